@@ -1,0 +1,220 @@
+"""ctypes binding for oracle/libvxoracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product path (libvoxhip.so and its Python/C++ front ends) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libvxoracle.so")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "vx_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "libvxoracle.so"])
+    return _SO
+
+
+class GridInfo(C.Structure):
+    _fields_ = [("bmin", C.c_float * 3), ("bmax", C.c_float * 3), ("center", C.c_float * 3), ("dim", C.c_uint64 * 3)]
+
+
+AABB = np.dtype([("mn", np.float32, 3), ("mx", np.float32, 3)])
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        fp, ip, u32p, u64p = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+        L.vxo_grid_info_compute.argtypes = [fp, C.c_size_t, C.c_float, C.POINTER(GridInfo)]
+        L.vxo_tri_box_overlap.argtypes = [fp] * 5
+        L.vxo_tri_box_overlap.restype = C.c_int
+        L.vxo_tri_box_overlap_ss.argtypes = [fp] * 5
+        L.vxo_tri_box_overlap_ss.restype = C.c_int
+        L.vxo_bool_num_words.argtypes = [C.POINTER(GridInfo)]
+        L.vxo_bool_num_words.restype = C.c_uint64
+        common = [fp, C.c_size_t, ip, C.c_size_t, C.c_float, C.c_int, C.c_int]
+        L.vxo_build_bool.argtypes = common + [u32p]
+        L.vxo_build_bool.restype = C.c_uint64
+        L.vxo_bool_aabbs.argtypes = [u32p, u64p, C.c_float, fp, C.c_void_p, C.c_uint64]
+        L.vxo_bool_aabbs.restype = C.c_uint64
+        L.vxo_build_aabbstruct.argtypes = common + [C.c_void_p, C.c_uint64, u64p]
+        L.vxo_build_aabbstruct.restype = C.c_uint64
+        L.vxo_build_vec.argtypes = common + [C.c_void_p, C.c_uint64]
+        L.vxo_build_vec.restype = C.c_uint64
+        L.vxo_hits.argtypes = common + [u32p, C.c_uint64]
+        L.vxo_hits.restype = C.c_uint64
+        L.vxo_morton3d.argtypes = [C.c_uint32] * 3
+        L.vxo_morton3d.restype = C.c_uint64
+        L.vxo_octree_build.argtypes = [fp, C.c_size_t, ip, C.c_size_t, C.c_float, C.c_uint64, C.c_int]
+        L.vxo_octree_build.restype = C.c_void_p
+        for name in ("vxo_octree_num_items", "vxo_octree_num_nodes", "vxo_octree_bytes"):
+            getattr(L, name).argtypes = [C.c_void_p]
+            getattr(L, name).restype = C.c_uint64
+        L.vxo_octree_copy_items.argtypes = [C.c_void_p, u64p]
+        L.vxo_octree_copy_nodes.argtypes = [C.c_void_p, u32p]
+        L.vxo_octree_root.argtypes = [C.c_void_p, fp, fp]
+        L.vxo_octree_aabbs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.vxo_octree_aabbs.restype = C.c_uint64
+        L.vxo_octree_free.argtypes = [C.c_void_p]
+        L.vxo_hit_aabb.argtypes = [C.c_void_p, fp, fp]
+        L.vxo_hit_aabb.restype = C.c_float
+        L.vxo_trace_brute.argtypes = [C.c_void_p, C.c_uint64, fp, C.c_uint64, C.c_float, C.c_float, C.c_int, fp, u32p]
+        L.vxo_primary_rays.argtypes = [fp, fp, C.c_uint32, C.c_uint32, fp]
+        _lib = L
+    return _lib
+
+
+def _f(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _i(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _u32(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def _u64(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint64))
+
+
+def _mesh(verts, idx):
+    v = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)
+    i = np.ascontiguousarray(idx, dtype=np.int32).reshape(-1, 3)
+    return v, i
+
+
+def grid_info(verts, vs):
+    v = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1)
+    gi = GridInfo()
+    lib().vxo_grid_info_compute(_f(v), v.size, np.float32(vs), C.byref(gi))
+    return dict(bmin=np.array(gi.bmin, dtype=np.float32), bmax=np.array(gi.bmax, dtype=np.float32),
+                center=np.array(gi.center, dtype=np.float32), dim=tuple(int(d) for d in gi.dim), _c=gi)
+
+
+def tri_box_overlap(c, h, v0, v1, v2, ss=False):
+    a = [np.ascontiguousarray(x, dtype=np.float32) for x in (c, h, v0, v1, v2)]
+    fn = lib().vxo_tri_box_overlap_ss if ss else lib().vxo_tri_box_overlap
+    return bool(fn(*[_f(x) for x in a]))
+
+
+def build_bool(verts, idx, vs, threads=0, sat=-1):
+    """-> (words uint32[ceil(N/32)], set_calls, grid_info).  VoxelBuilder<VoxelGridBool,...>::buildVoxelGrid."""
+    v, i = _mesh(verts, idx)
+    gi = grid_info(v, vs)
+    nw = int(lib().vxo_bool_num_words(C.byref(gi["_c"])))
+    words = np.zeros(max(nw, 1), dtype=np.uint32)
+    calls = lib().vxo_build_bool(_f(v), v.shape[0], _i(i), i.shape[0], np.float32(vs), threads, sat, _u32(words))
+    return words[:nw], int(calls), gi
+
+
+def bool_aabbs(words, gi, vs):
+    """VoxelGridBool::getAabbs."""
+    dim = np.array(gi["dim"], dtype=np.uint64)
+    org = np.ascontiguousarray(gi["bmin"], dtype=np.float32)
+    w = np.ascontiguousarray(words, dtype=np.uint32)
+    if w.size == 0:
+        return np.zeros(0, dtype=AABB)
+    n = int(lib().vxo_bool_aabbs(_u32(w), _u64(dim), np.float32(vs), _f(org), None, 0))
+    out = np.zeros(n, dtype=AABB)
+    if n:
+        lib().vxo_bool_aabbs(_u32(w), _u64(dim), np.float32(vs), _f(org), out.ctypes.data, n)
+    return out
+
+
+def build_aabbstruct(verts, idx, vs, threads=0, sat=-1):
+    """-> (aabbs, memory_bytes).  VoxelGridAABBstruct path (dense 28 B/voxel on the CPU: keep grids small)."""
+    v, i = _mesh(verts, idx)
+    by = C.c_uint64(0)
+    n = int(lib().vxo_build_aabbstruct(_f(v), v.shape[0], _i(i), i.shape[0], np.float32(vs), threads, sat, None, 0, C.byref(by)))
+    out = np.zeros(n, dtype=AABB)
+    if n:
+        lib().vxo_build_aabbstruct(_f(v), v.shape[0], _i(i), i.shape[0], np.float32(vs), threads, sat, out.ctypes.data, n, C.byref(by))
+    return out, int(by.value)
+
+
+def build_vec(verts, idx, vs, threads=0, sat=-1, cap=None):
+    """VoxelGridVec path: one Aabb per setVoxel call, duplicates kept, reference order."""
+    v, i = _mesh(verts, idx)
+    if cap is None:
+        cap = int(lib().vxo_build_vec(_f(v), v.shape[0], _i(i), i.shape[0], np.float32(vs), threads, sat, None, 0))
+    out = np.zeros(cap, dtype=AABB)
+    n = int(lib().vxo_build_vec(_f(v), v.shape[0], _i(i), i.shape[0], np.float32(vs), threads, sat, out.ctypes.data if cap else None, cap))
+    return out[:n]
+
+
+def hits(verts, idx, vs, threads=0, sat=-1):
+    v, i = _mesh(verts, idx)
+    n = int(lib().vxo_hits(_f(v), v.shape[0], _i(i), i.shape[0], np.float32(vs), threads, sat, None, 0))
+    out = np.zeros((max(n, 1), 3), dtype=np.uint32)
+    lib().vxo_hits(_f(v), v.shape[0], _i(i), i.shape[0], np.float32(vs), threads, sat, _u32(out), n)
+    return out[:n]
+
+
+def morton3d(x, y, z):
+    return int(lib().vxo_morton3d(int(x), int(y), int(z)))
+
+
+NODE = np.dtype([("children", np.uint32, 8), ("start", np.uint32), ("count", np.uint32)])
+
+
+def octree(verts, idx, vs, max_items=16, threads=1):
+    """Octree(path, vs, maxItemsPerLeaf) -> dict(items, nodes, aabbs, bytes, root_min, root_max)."""
+    v, i = _mesh(verts, idx)
+    h = lib().vxo_octree_build(_f(v), v.shape[0], _i(i), i.shape[0], np.float32(vs), max_items, threads)
+    if not h:
+        raise RuntimeError("We support up to 21 bits per axis (max 2^21 voxels per dimension)!")
+    try:
+        ni, nn = int(lib().vxo_octree_num_items(h)), int(lib().vxo_octree_num_nodes(h))
+        items = np.zeros(max(ni, 1), dtype=np.uint64)
+        nodes = np.zeros(max(nn, 1), dtype=NODE)
+        lib().vxo_octree_copy_items(h, _u64(items))
+        lib().vxo_octree_copy_nodes(h, nodes.ctypes.data_as(C.POINTER(C.c_uint32)))
+        aabbs = np.zeros(max(ni, 1), dtype=AABB)
+        na = int(lib().vxo_octree_aabbs(h, aabbs.ctypes.data, ni))
+        mn, mx = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        lib().vxo_octree_root(h, _f(mn), _f(mx))
+        return dict(items=items[:ni], nodes=nodes[:nn], aabbs=aabbs[:na], bytes=int(lib().vxo_octree_bytes(h)),
+                    root_min=mn, root_max=mx)
+    finally:
+        lib().vxo_octree_free(h)
+
+
+def hit_aabb(box, o, d):
+    b = np.zeros(1, dtype=AABB)
+    b[0] = box
+    o = np.ascontiguousarray(o, dtype=np.float32)
+    d = np.ascontiguousarray(d, dtype=np.float32)
+    return float(lib().vxo_hit_aabb(b.ctypes.data, _f(o), _f(d)))
+
+
+def trace_brute(aabbs, rays, tmin=0.001, tmax=10000.0, threads=None):
+    """First hit per ray by brute force over the AABB list -> (t float32[R] (-1 = miss), prim uint32[R])."""
+    a = np.ascontiguousarray(aabbs, dtype=AABB)
+    r = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+    t = np.zeros(r.shape[0], dtype=np.float32)
+    p = np.zeros(r.shape[0], dtype=np.uint32)
+    if threads is None:
+        threads = os.cpu_count() or 1
+    lib().vxo_trace_brute(a.ctypes.data if a.size else None, a.size, _f(r), r.shape[0], np.float32(tmin), np.float32(tmax), threads, _f(t), _u32(p))
+    return t, p
+
+
+def primary_rays(view_inv, proj_inv, W, H):
+    vi = np.ascontiguousarray(view_inv, dtype=np.float32).reshape(16)
+    pi = np.ascontiguousarray(proj_inv, dtype=np.float32).reshape(16)
+    rays = np.zeros((H * W, 6), dtype=np.float32)
+    lib().vxo_primary_rays(_f(vi), _f(pi), W, H, _f(rays))
+    return rays
