@@ -1,0 +1,178 @@
+/*
+ * voxhip.h -- C ABI of libvoxhip.so: MI355X (gfx950) implementation of the reference's voxelizer hot path.
+ *
+ * The reference (MatBayern/Raytracing-Voxilizer-Vulkan-Intresection) has no FFI layer; its boundary for this
+ * path is the C++ template API  VoxelBuilder<T>{path}.buildVoxelGrid(vs) -> T,  T::getAabbs(),  Octree{path,vs}
+ * and the GLSL intersection shader raytrace.rint.  Each entry point below names the reference interface it
+ * replaces (paths relative to the reference root).  The C++ facade in
+ * raytracing-voxilizer-vulkan-intresection_amd/cpp/ re-creates the reference classes on top of this ABI.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; handles are opaque; every function returns vx_status (VX_OK == 0) unless
+ *     stated otherwise; vx_last_error() gives the message of the calling thread's last failure.
+ *   - "host" pointers are ordinary memory, "dev" pointers are HIP device memory on the handle's device.
+ *   - `stream` arguments are hipStream_t passed as void* (NULL = the default stream).
+ *   - handles are not thread-safe; distinct handles may be used from distinct threads.
+ *   - all compute runs in HIP kernels; there is no CPU fallback: without a usable device the compute entry
+ *     points fail with VX_ERR_NO_DEVICE.
+ *
+ * Data contracts (identical to the reference)
+ *   - occupancy bitmask: uint32 words, LSB first, voxel index i = x + X*(y + Y*z)          (voxelgrid.hpp:37-40,
+ *     voxelgridBool.cpp:54-68)
+ *   - vx_aabb: 6 x float32, tightly packed, 24 B                                           (shaders/host_device.h:117-121)
+ *   - AABB list order: VX_GRID_BOOL / VX_GRID_AABBSTRUCT ascending voxel index, no duplicates;
+ *     VX_GRID_VEC triangle-major then z,y,x with duplicates; octree ascending Morton code with duplicates.
+ */
+#ifndef VOXHIP_H
+#define VOXHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum vx_status {
+    VX_OK = 0,
+    VX_ERR_INVALID_ARG = 1,
+    VX_ERR_PATH = 2,          /* "Path does not exist!"                  VoxelBuilder.hpp:54-56, octTree.hpp:300-302 */
+    VX_ERR_PARSE = 3,         /* "Colud not get valid reader! ..."       VoxelBuilder.hpp:63-65 */
+    VX_ERR_OUT_OF_BOUNDS = 4, /* "Index out of bounds"                   voxelgrid.hpp:68-70, voxelgridBool.cpp:57-59 */
+    VX_ERR_MORTON_BITS = 5,   /* "We support up to 21 bits per axis ..." octTree.hpp:583-585 */
+    VX_ERR_NO_DEVICE = 6,
+    VX_ERR_HIP = 7,
+    VX_ERR_CAPACITY = 8,      /* caller buffer too small, or an internal 32-bit counter would overflow */
+    VX_ERR_UNSUPPORTED = 9
+} vx_status;
+
+typedef struct vx_aabb { float minimum[3]; float maximum[3]; } vx_aabb; /* shaders/host_device.h:117-121 */
+
+typedef enum vx_grid_kind {
+    VX_GRID_BOOL = 0,       /* VoxelGridBool        voxelgridBool.{hpp,cpp} */
+    VX_GRID_AABBSTRUCT = 1, /* VoxelGridAABBstruct  voxelgridAABBstruct.{hpp,cpp} */
+    VX_GRID_VEC = 2         /* VoxelGridVec         voxelgridVecEncoding.{hpp,cpp} */
+} vx_grid_kind;
+
+typedef struct vx_mesh vx_mesh;     /* parsed OBJ: what VoxelBuilder keeps in m_attribs / m_shapes */
+typedef struct vx_grid vx_grid;     /* a VoxelGrid<T> */
+typedef struct vx_octree vx_octree; /* an Octree */
+
+typedef struct vx_grid_desc {
+    uint64_t dim[3];     /* m_x, m_y, m_z                                             voxelgrid.hpp:19-21 */
+    float voxel_size;    /* m_voxelSize */
+    float origin[3];     /* m_org (== bbox min for built grids) */
+    float bbox_min[3], bbox_max[3], bbox_center[3]; /* VoxelBuilder.hpp:198-224 (zero for vx_grid_create) */
+    uint64_t num_words;  /* ceil(X*Y*Z/32) */
+    uint64_t set_calls;  /* m_voxelSet: number of setVoxel calls (duplicates counted)  voxelgridBool.cpp:67 */
+    uint64_t occupied;   /* distinct occupied voxels (popcount of the bitmask) */
+    uint64_t triangles;  /* "Total triangles processed"                                VoxelBuilder.hpp:417 */
+    int32_t kind;        /* vx_grid_kind */
+    int32_t device;
+} vx_grid_desc;
+
+typedef struct vx_voxelize_opts {
+    int32_t sat_variant;  /* 0: triBoxOverlap (serial driver, VoxelBuilder.hpp:118-162, inParaell=false);
+                             1: triBoxOverlapSchwarzSeidel (threaded driver, :226-335, inParaell=true) */
+    int32_t reserved;
+    uint64_t word_begin;  /* multi-GPU shard: only bitmask words [word_begin, word_end) are written by this    */
+    uint64_t word_end;    /* call (both 0 = whole grid).  Triangle range for VX_GRID_VEC shards:               */
+    uint64_t tri_begin;   /* only triangles [tri_begin, tri_end) are voxelized (both 0 = all).                 */
+    uint64_t tri_end;
+    void* stream;         /* hipStream_t the grid's kernels run on */
+} vx_voxelize_opts;
+
+/* ---- library ------------------------------------------------------------------------------------------- */
+const char* vx_last_error(void);
+const char* vx_status_string(vx_status s);
+int vx_device_count(void);           /* HIP devices visible (0 when there is none / no driver) */
+vx_status vx_set_device(int device); /* device used by handles created afterwards on this thread */
+vx_status vx_release_cached_memory(void); /* return the library's pooled device blocks to HIP */
+
+/* ---- mesh: replaces VoxelBuilder::readObjFile (VoxelBuilder.hpp:51-70) / Octree::readObjFile (octTree.hpp:298-316) */
+vx_status vx_mesh_load_obj(const char* path, vx_mesh** out);
+vx_status vx_mesh_from_arrays(const float* host_xyz, size_t num_vertices, const int32_t* host_tri_indices,
+                              size_t num_triangles, vx_mesh** out);
+/* borrow arrays already resident in HBM (no copy; they must outlive the mesh) */
+vx_status vx_mesh_from_device(const float* dev_xyz, size_t num_vertices, const int32_t* dev_tri_indices,
+                              size_t num_triangles, vx_mesh** out);
+size_t vx_mesh_num_vertices(const vx_mesh* m);
+size_t vx_mesh_num_triangles(const vx_mesh* m);
+/* host copies (NULL for vx_mesh_from_device meshes) */
+const float* vx_mesh_host_vertices(const vx_mesh* m);
+const int32_t* vx_mesh_host_indices(const vx_mesh* m);
+void vx_mesh_free(vx_mesh* m);
+
+/* ---- voxelize: replaces VoxelBuilder<T,inParaell>::buildVoxelGrid (VoxelBuilder.hpp:338-542) --------------- */
+vx_status vx_voxelize(const vx_mesh* mesh, float voxel_size, vx_grid_kind kind, const vx_voxelize_opts* opts /*NULL ok*/,
+                      vx_grid** out);
+/* same, re-using an existing grid handle's device buffers (steady-state loops; no allocation when sizes repeat) */
+vx_status vx_voxelize_into(const vx_mesh* mesh, float voxel_size, const vx_voxelize_opts* opts, vx_grid* grid);
+
+/* ---- grid: replaces VoxelGrid<T> and its three subclasses ------------------------------------------------ */
+/* VoxelGrid ctor (voxelgrid.hpp:52-62): an empty grid of x*y*z voxels */
+vx_status vx_grid_create(vx_grid_kind kind, uint64_t x, uint64_t y, uint64_t z, float voxel_size, const float origin[3],
+                         void* stream, vx_grid** out);
+vx_status vx_grid_describe(const vx_grid* g, vx_grid_desc* out);
+/* setVoxel (voxelgridBool.cpp:54-68, voxelgridAABBstruct.cpp:23-47, voxelgridVecEncoding.cpp:19-39) */
+vx_status vx_grid_set_voxel(vx_grid* g, uint64_t x, uint64_t y, uint64_t z);
+/* occupancy test of one voxel (the reference's VoxelGrid::getVoxel is broken for the Bool grid, voxelgrid.hpp:66-72) */
+vx_status vx_grid_test_voxel(const vx_grid* g, uint64_t x, uint64_t y, uint64_t z, int* occupied);
+/* getCorrds (voxelgrid.hpp:91-100) */
+vx_status vx_grid_coords(const vx_grid* g, uint64_t x, uint64_t y, uint64_t z, float out_xyz[3]);
+/* getMemoryUsageBytes (voxelgrid.hpp:115-122): Bool 4*ceil(N/32); AABBstruct 28*N; Vec 24*set_calls */
+uint64_t vx_grid_bytes(const vx_grid* g);
+/* bitmask access */
+vx_status vx_grid_bitmask(const vx_grid* g, uint32_t* host_words, uint64_t capacity_words);
+const uint32_t* vx_grid_bitmask_device(const vx_grid* g);
+uint32_t* vx_grid_bitmask_device_mut(vx_grid* g); /* for the multi-GPU exchange; call vx_grid_refresh afterwards */
+vx_status vx_grid_refresh(vx_grid* g);            /* recount + rebuild derived data after the bitmask was written externally */
+/* getAabbs (voxelgridBool.cpp:18-52, voxelgridAABBstruct.cpp:10-22, voxelgridVecEncoding.cpp:15-18).
+ * *count receives the list length; at most `capacity` entries are written (capacity 0 = size query). */
+vx_status vx_grid_aabbs(const vx_grid* g, vx_aabb* host_out, uint64_t capacity, uint64_t* count);
+vx_status vx_grid_aabbs_device(const vx_grid* g, vx_aabb* dev_out, uint64_t capacity, uint64_t* count);
+void vx_grid_free(vx_grid* g);
+
+/* ---- octree: replaces Octree (octTree.hpp:487-523) ------------------------------------------------------- */
+typedef struct vx_octree_node { uint32_t children[8]; uint32_t start; uint32_t count; } vx_octree_node; /* octTree.hpp:251-277 */
+vx_status vx_octree_build(const vx_mesh* mesh, float voxel_size, uint64_t max_items_per_leaf, void* stream, vx_octree** out);
+uint64_t vx_octree_num_items(const vx_octree* o);
+uint64_t vx_octree_num_nodes(const vx_octree* o);
+uint64_t vx_octree_bytes(const vx_octree* o); /* getMemoryUsageBytes octTree.hpp:512-523: 8*items + 40*nodes */
+vx_status vx_octree_items(const vx_octree* o, uint64_t* host_morton, uint64_t capacity);
+vx_status vx_octree_nodes(const vx_octree* o, vx_octree_node* host_nodes, uint64_t capacity);
+vx_status vx_octree_root_bounds(const vx_octree* o, float mn[3], float mx[3]);
+vx_status vx_octree_aabbs(const vx_octree* o, vx_aabb* host_out, uint64_t capacity, uint64_t* count); /* getAabbs :502-510 */
+vx_status vx_octree_aabbs_device(const vx_octree* o, vx_aabb* dev_out, uint64_t capacity, uint64_t* count);
+void vx_octree_free(vx_octree* o);
+
+/* ---- rays: replaces the procedural-hit stage  raytrace.rint:46-71 under traceRayEXT (raytrace.rgen:49-64) --
+ * For every ray the closest accepted hit over all occupied voxels' AABBs:  t = hitAabb() of that box,
+ * accepted iff t > 0 and tmin <= t <= tmax;  prim = index of the box in vx_grid_aabbs() order of the Bool grid
+ * (== gl_PrimitiveID); miss: t = -1, prim = 0xFFFFFFFF.  Rays: 6 float32 each (origin xyz, direction xyz).
+ * The reference's ray interval is tmin 0.001, tmax 10000 (raytrace.rgen:50-51).                               */
+typedef struct vx_hit { uint32_t ray; uint32_t prim; float t; } vx_hit;
+vx_status vx_trace(const vx_grid* g, const float* host_rays, uint64_t num_rays, float tmin, float tmax,
+                   float* host_t /*NULL ok*/, uint32_t* host_prim /*NULL ok*/, uint64_t* num_hits /*NULL ok*/);
+/* device buffers; optional compacted hit list (ballot/prefix compaction) of capacity num_rays; *dev_num_hits is a
+ * device uint64 counter the call zeroes first */
+vx_status vx_trace_device(const vx_grid* g, const float* dev_rays, uint64_t num_rays, float tmin, float tmax,
+                          float* dev_t /*NULL ok*/, uint32_t* dev_prim /*NULL ok*/, vx_hit* dev_hits /*NULL ok*/,
+                          uint64_t* dev_num_hits /*NULL ok*/);
+/* primary rays generated in-kernel from the reference camera model (raytrace.rgen:41-47): pixel (px,py) of a
+ * width x height image, column-major 4x4 viewInverse / projInverse; outputs indexed py*width+px */
+vx_status vx_trace_primary_device(const vx_grid* g, const float view_inverse[16], const float proj_inverse[16],
+                                  uint32_t width, uint32_t height, float tmin, float tmax, float* dev_t,
+                                  uint32_t* dev_prim /*NULL ok*/);
+
+/* ---- multi-GPU helpers (host arithmetic only) ----------------------------------------------------------------
+ * Word-aligned shard of the bitmask for rank r of n: contributions of different ranks are word-disjoint, so an
+ * all-gather of the shards (or a sum/max all-reduce of zero-padded buffers) equals the OR of the full masks. */
+void vx_shard_words(uint64_t num_words, int rank, int world, uint64_t* word_begin, uint64_t* word_end,
+                    uint64_t* padded_shard_words);
+void vx_shard_range(uint64_t count, int rank, int world, uint64_t* begin, uint64_t* end);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOXHIP_H */

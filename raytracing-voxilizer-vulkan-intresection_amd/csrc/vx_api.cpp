@@ -1,0 +1,998 @@
+// vx_api.cpp -- the C ABI declared in include/voxhip.h: handles, device-memory pool, launch sequencing.
+// All compute happens in the kernels of vx_kernels.hip; there is no CPU compute path in this library.
+#include "vx_internal.h"
+
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#pragma clang fp contract(off)
+
+namespace vx {
+int load_obj(const char* path, std::vector<float>& verts, std::vector<int32_t>& tris, std::string& msg);
+}
+
+namespace {
+
+thread_local std::string g_err;
+thread_local int g_device = 0;
+
+vx_status fail(vx_status s, const std::string& m)
+{
+    g_err = m;
+    return s;
+}
+
+#define VX_HIP(expr)                                                                                       \
+    do {                                                                                                   \
+        hipError_t e__ = (expr);                                                                           \
+        if (e__ != hipSuccess) return fail(VX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+#define VX_TRY(expr)                 \
+    do {                             \
+        vx_status s__ = (expr);      \
+        if (s__ != VX_OK) return s__; \
+    } while (0)
+
+// ---- pooled device memory: hipMalloc/hipFree are slow and synchronising, steady-state loops must not call them ----
+constexpr int kMaxDev = 16;
+struct Pool {
+    std::mutex mu;
+    std::multimap<size_t, void*> free_blocks;
+    std::unordered_map<void*, size_t> live;
+};
+Pool g_pool[kMaxDev];
+
+size_t round_size(size_t b)
+{
+    if (b < 256) b = 256;
+    if (b >= (1u << 20)) return (b + (2u << 20) - 1) / (2u << 20) * (2u << 20);
+    size_t p = 256;
+    while (p < b) p <<= 1;
+    return p;
+}
+
+hipError_t pool_alloc(int dev, size_t bytes, void** out)
+{
+    const size_t sz = round_size(bytes);
+    Pool& P = g_pool[dev];
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        auto it = P.free_blocks.lower_bound(sz);
+        if (it != P.free_blocks.end() && it->first <= sz * 2) {
+            *out = it->second;
+            P.live[*out] = it->first;
+            P.free_blocks.erase(it);
+            return hipSuccess;
+        }
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, sz);
+    if (e != hipSuccess) {
+        // drop the cache and retry once
+        vx_release_cached_memory();
+        e = hipMalloc(&p, sz);
+        if (e != hipSuccess) return e;
+    }
+    std::lock_guard<std::mutex> lk(P.mu);
+    P.live[p] = sz;
+    *out = p;
+    return hipSuccess;
+}
+
+void pool_free(int dev, void* p)
+{
+    if (!p) return;
+    Pool& P = g_pool[dev];
+    std::lock_guard<std::mutex> lk(P.mu);
+    auto it = P.live.find(p);
+    if (it == P.live.end()) return;
+    P.free_blocks.emplace(it->second, p);
+    P.live.erase(it);
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int dev = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap && p) return hipSuccess;
+        release();
+        hipError_t e = pool_alloc(dev, bytes, &p);
+        if (e == hipSuccess) cap = round_size(bytes);
+        return e;
+    }
+    void release()
+    {
+        if (p) pool_free(dev, p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) { prev = -1; }
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+vx_status need_device(int dev)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(VX_ERR_NO_DEVICE, "no HIP device available: libvoxhip has no CPU path");
+    if (dev < 0 || dev >= n || dev >= kMaxDev) return fail(VX_ERR_INVALID_ARG, "device index out of range");
+    return VX_OK;
+}
+
+// small per-handle scratch in device memory
+struct Small {
+    unsigned long long keys[6];
+    float bbox[6];
+    float pad0[2];
+    unsigned long long set_calls;
+    unsigned long long total_a;
+    unsigned long long total_b;
+    unsigned long long nhits;
+};
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------
+struct vx_mesh {
+    int device = 0;
+    std::vector<float> hv;
+    std::vector<int32_t> hi;
+    size_t nv = 0, nt = 0;
+    const float* dv = nullptr;
+    const int32_t* di = nullptr;
+    DevBuf bv, bi;
+    bool borrowed = false;
+    bool uploaded = false;
+};
+
+struct vx_grid {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int kind = VX_GRID_BOOL;
+    vx::GridParams g{};
+    float bbmin[3] = {0, 0, 0}, bbmax[3] = {0, 0, 0}, bbc[3] = {0, 0, 0};
+    uint64_t triangles = 0;
+    uint32_t cdim[3] = {0, 0, 0};
+    DevBuf words, cwords, wprefix, recs, units, ubase, umask, hbase, scantmp, small, vec;
+    bool coarse_valid = false, prefix_valid = false, counts_valid = true;
+    uint64_t occupied = 0, set_calls = 0, host_set_calls = 0;
+    uint64_t vec_count = 0;
+    void set_dev(int d)
+    {
+        device = d;
+        for (DevBuf* b : {&words, &cwords, &wprefix, &recs, &units, &ubase, &umask, &hbase, &scantmp, &small, &vec}) b->dev = d;
+    }
+    void release_all()
+    {
+        for (DevBuf* b : {&words, &cwords, &wprefix, &recs, &units, &ubase, &umask, &hbase, &scantmp, &small, &vec}) b->release();
+    }
+};
+
+struct vx_octree {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    float vs = 0.f;
+    float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
+    uint64_t dim[3] = {0, 0, 0};
+    uint32_t bits = 0;
+    uint64_t max_items = 16;
+    uint64_t nitems = 0;
+    DevBuf items;  // sorted Morton codes
+    std::vector<vx_octree_node> nodes;
+    bool built_tree = false;
+};
+
+namespace {
+
+vx_status mesh_to_device(vx_mesh* m)
+{
+    if (m->uploaded || m->borrowed) return VX_OK;
+    VX_TRY(need_device(m->device));
+    m->bv.dev = m->bi.dev = m->device;
+    VX_HIP(m->bv.ensure(m->nv * 12 + 16));
+    VX_HIP(m->bi.ensure(m->nt * 12 + 16));
+    if (m->nv) VX_HIP(hipMemcpy(m->bv.p, m->hv.data(), m->nv * 12, hipMemcpyHostToDevice));
+    if (m->nt) VX_HIP(hipMemcpy(m->bi.p, m->hi.data(), m->nt * 12, hipMemcpyHostToDevice));
+    m->dv = m->bv.as<float>();
+    m->di = m->bi.as<int32_t>();
+    m->uploaded = true;
+    return VX_OK;
+}
+
+// bbox + dims: computeBboxFromAttrib (VoxelBuilder.hpp:198-224) on the device, dims on the host (:347-349)
+struct Extent {
+    float mn[3], mx[3], ctr[3];
+    uint64_t dim[3];
+};
+
+vx_status compute_extent(const vx_mesh* m, float vs, Small* dsmall, hipStream_t s, Extent* e)
+{
+    vx::launch_bbox(m->dv, m->nv, dsmall->keys, dsmall->bbox, s);
+    float bb[6];
+    VX_HIP(hipMemcpyAsync(bb, dsmall->bbox, sizeof(bb), hipMemcpyDeviceToHost, s));
+    VX_HIP(hipStreamSynchronize(s));
+    for (int a = 0; a < 3; ++a) {
+        e->mn[a] = bb[a];
+        e->mx[a] = bb[3 + a];
+        e->ctr[a] = (bb[a] + bb[3 + a]) * 0.5f;  // VoxelBuilder.hpp:221
+        if (m->nv == 0) { e->dim[a] = 0; continue; }
+        const float q = std::ceil((e->mx[a] - e->mn[a]) / vs);  // :347-349
+        if (!(q >= 0.0f) || q > 65535.0f) return fail(VX_ERR_CAPACITY, "grid dimension outside [0, 65535]: voxel size too small for this mesh");
+        e->dim[a] = (uint64_t)q;
+    }
+    return VX_OK;
+}
+
+vx_status check_voxel_size(float vs)
+{
+    if (!(vs > 0.0f) || !std::isfinite(vs)) return fail(VX_ERR_INVALID_ARG, "voxel size must be a finite positive float");
+    return VX_OK;
+}
+
+void fill_params(vx::GridParams& g, const float org[3], float vs, const uint64_t dim[3])
+{
+    for (int a = 0; a < 3; ++a) { g.org[a] = org[a]; g.dim[a] = (uint32_t)dim[a]; }
+    g.vs = vs;
+    g.half = vs * 0.5f;
+    g.nvox = dim[0] * dim[1] * dim[2];
+    g.nwords = (g.nvox + 31) / 32;
+}
+
+constexpr uint64_t kMaxVoxels = 1ull << 37;  // 16 GiB of bitmask
+
+// The shared front half of buildVoxelGrid for grids and the octree: records, unit counts, unit bases.
+vx_status run_setup(const vx_mesh* m, const vx::GridParams& g, int sat, uint64_t tb, uint32_t ntri, uint32_t zlo, uint32_t zhi, DevBuf& recs,
+                    DevBuf& units, DevBuf& ubase, DevBuf& scantmp, Small* ds, hipStream_t s, uint64_t* total_units)
+{
+    VX_HIP(recs.ensure((size_t)ntri * sizeof(vx::TriRec) + 64));
+    VX_HIP(units.ensure(((size_t)ntri + 1) * 4));
+    VX_HIP(ubase.ensure(((size_t)ntri + 2) * 4));
+    VX_HIP(scantmp.ensure(vx::scan_tmp_bytes(ntri)));
+    vx::launch_tri_setup(m->dv, m->di, tb, ntri, g, sat, zlo, zhi, recs.as<vx::TriRec>(), units.as<uint32_t>(), s);
+    vx::launch_scan_u32(units.as<uint32_t>(), ubase.as<uint32_t>(), ntri, false, scantmp.p, &ds->total_a, s);
+    unsigned long long tot = 0;
+    VX_HIP(hipMemcpyAsync(&tot, &ds->total_a, 8, hipMemcpyDeviceToHost, s));
+    VX_HIP(hipStreamSynchronize(s));
+    if (tot >= 0xFFFFFFFFull) return fail(VX_ERR_CAPACITY, "more than 2^32 candidate row segments: shard the mesh or the grid");
+    *total_units = tot;
+    return VX_OK;
+}
+
+vx_status ensure_prefix(vx_grid* g)
+{
+    if (g->prefix_valid) return VX_OK;
+    DeviceGuard dg(g->device);
+    VX_HIP(g->wprefix.ensure((size_t)(g->g.nwords + 2) * 4));
+    VX_HIP(g->scantmp.ensure(vx::scan_tmp_bytes(g->g.nwords)));
+    Small* ds = g->small.as<Small>();
+    vx::launch_scan_u32(g->words.as<uint32_t>(), g->wprefix.as<uint32_t>(), g->g.nwords, true, g->scantmp.p, &ds->total_b, g->stream);
+    unsigned long long tot = 0;
+    VX_HIP(hipMemcpyAsync(&tot, &ds->total_b, 8, hipMemcpyDeviceToHost, g->stream));
+    VX_HIP(hipStreamSynchronize(g->stream));
+    if (tot >= 0xFFFFFFFFull) return fail(VX_ERR_CAPACITY, "more than 2^32 occupied voxels");
+    g->occupied = tot;
+    g->prefix_valid = true;
+    return VX_OK;
+}
+
+vx_status ensure_coarse(vx_grid* g)
+{
+    if (g->coarse_valid) return VX_OK;
+    DeviceGuard dg(g->device);
+    for (int a = 0; a < 3; ++a) g->cdim[a] = (g->g.dim[a] + vx::kCoarse - 1) / vx::kCoarse;
+    const uint64_t nc = (uint64_t)g->cdim[0] * g->cdim[1] * g->cdim[2];
+    VX_HIP(g->cwords.ensure((size_t)((nc + 31) / 32 + 1) * 4));
+    vx::launch_build_coarse(g->words.as<uint32_t>(), g->g, g->cdim, g->cwords.as<uint32_t>(), g->stream);
+    g->coarse_valid = true;
+    return VX_OK;
+}
+
+vx_status sync_counts(vx_grid* g)
+{
+    if (g->counts_valid) return VX_OK;
+    DeviceGuard dg(g->device);
+    unsigned long long sc = 0;
+    VX_HIP(hipMemcpyAsync(&sc, &g->small.as<Small>()->set_calls, 8, hipMemcpyDeviceToHost, g->stream));
+    VX_HIP(hipStreamSynchronize(g->stream));
+    g->set_calls = sc + g->host_set_calls;
+    g->counts_valid = true;
+    return VX_OK;
+}
+
+vx_status init_grid_storage(vx_grid* g)
+{
+    VX_HIP(g->small.ensure(sizeof(Small)));
+    VX_HIP(g->words.ensure((size_t)(g->g.nwords + 2) * 4));
+    VX_HIP(hipMemsetAsync(g->words.p, 0, (size_t)(g->g.nwords + 2) * 4, g->stream));
+    VX_HIP(hipMemsetAsync(&g->small.as<Small>()->set_calls, 0, 8, g->stream));
+    g->coarse_valid = g->prefix_valid = false;
+    g->counts_valid = true;
+    g->occupied = g->set_calls = g->host_set_calls = g->vec_count = 0;
+    return VX_OK;
+}
+
+}  // namespace
+
+// ============================================================================================================
+extern "C" {
+
+const char* vx_last_error(void) { return g_err.c_str(); }
+
+const char* vx_status_string(vx_status s)
+{
+    switch (s) {
+        case VX_OK: return "ok";
+        case VX_ERR_INVALID_ARG: return "invalid argument";
+        case VX_ERR_PATH: return "Path does not exist!";
+        case VX_ERR_PARSE: return "Colud not get valid reader!";
+        case VX_ERR_OUT_OF_BOUNDS: return "Index out of bounds";
+        case VX_ERR_MORTON_BITS: return "We support up to 21 bits per axis (max 2^21 voxels per dimension)!";
+        case VX_ERR_NO_DEVICE: return "no HIP device";
+        case VX_ERR_HIP: return "HIP runtime error";
+        case VX_ERR_CAPACITY: return "capacity exceeded";
+        case VX_ERR_UNSUPPORTED: return "unsupported";
+    }
+    return "unknown";
+}
+
+int vx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+vx_status vx_set_device(int device)
+{
+    VX_TRY(need_device(device));
+    g_device = device;
+    return VX_OK;
+}
+
+vx_status vx_release_cached_memory(void)
+{
+    int n = vx_device_count();
+    for (int d = 0; d < n && d < kMaxDev; ++d) {
+        std::vector<void*> blocks;
+        {
+            std::lock_guard<std::mutex> lk(g_pool[d].mu);
+            for (auto& kv : g_pool[d].free_blocks) blocks.push_back(kv.second);
+            g_pool[d].free_blocks.clear();
+        }
+        if (blocks.empty()) continue;
+        DeviceGuard dg(d);
+        for (void* p : blocks) (void)hipFree(p);
+    }
+    return VX_OK;
+}
+
+// ---- mesh ---------------------------------------------------------------------------------------------------
+vx_status vx_mesh_load_obj(const char* path, vx_mesh** out)
+{
+    if (!path || !out) return fail(VX_ERR_INVALID_ARG, "null argument");
+    vx_mesh* m = new vx_mesh();
+    std::string msg;
+    const int rc = vx::load_obj(path, m->hv, m->hi, msg);
+    if (rc == 1) { delete m; return fail(VX_ERR_PATH, "Path does not exist!"); }                                    // VoxelBuilder.hpp:54-56
+    if (rc == 2) { delete m; return fail(VX_ERR_PARSE, "Colud not get valid reader! Error message " + msg); }        // :63-65
+    m->nv = m->hv.size() / 3;
+    m->nt = m->hi.size() / 3;
+    m->device = g_device;
+    *out = m;
+    return VX_OK;
+}
+
+vx_status vx_mesh_from_arrays(const float* xyz, size_t nv, const int32_t* idx, size_t nt, vx_mesh** out)
+{
+    if (!out || (nv && !xyz) || (nt && !idx)) return fail(VX_ERR_INVALID_ARG, "null argument");
+    if (nv >= 0xFFFFFFFFull || nt >= 0xFFFFFFFEull) return fail(VX_ERR_CAPACITY, "mesh too large for 32-bit indices");
+    for (size_t i = 0; i < nt * 3; ++i)
+        if (idx[i] < 0 || (size_t)idx[i] >= nv) return fail(VX_ERR_INVALID_ARG, "triangle index out of range");
+    vx_mesh* m = new vx_mesh();
+    m->hv.assign(xyz, xyz + nv * 3);
+    m->hi.assign(idx, idx + nt * 3);
+    m->nv = nv;
+    m->nt = nt;
+    m->device = g_device;
+    *out = m;
+    return VX_OK;
+}
+
+vx_status vx_mesh_from_device(const float* dxyz, size_t nv, const int32_t* didx, size_t nt, vx_mesh** out)
+{
+    if (!out || (nv && !dxyz) || (nt && !didx)) return fail(VX_ERR_INVALID_ARG, "null argument");
+    if (nv >= 0xFFFFFFFFull || nt >= 0xFFFFFFFEull) return fail(VX_ERR_CAPACITY, "mesh too large for 32-bit indices");
+    VX_TRY(need_device(g_device));
+    vx_mesh* m = new vx_mesh();
+    m->nv = nv;
+    m->nt = nt;
+    m->dv = dxyz;
+    m->di = didx;
+    m->borrowed = true;
+    m->device = g_device;
+    *out = m;
+    return VX_OK;
+}
+
+size_t vx_mesh_num_vertices(const vx_mesh* m) { return m ? m->nv : 0; }
+size_t vx_mesh_num_triangles(const vx_mesh* m) { return m ? m->nt : 0; }
+const float* vx_mesh_host_vertices(const vx_mesh* m) { return (m && !m->borrowed) ? m->hv.data() : nullptr; }
+const int32_t* vx_mesh_host_indices(const vx_mesh* m) { return (m && !m->borrowed) ? m->hi.data() : nullptr; }
+void vx_mesh_free(vx_mesh* m)
+{
+    if (!m) return;
+    m->bv.release();
+    m->bi.release();
+    delete m;
+}
+
+// ---- voxelize -------------------------------------------------------------------------------------------------
+vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_opts* opts, vx_grid* g)
+{
+    if (!mesh_c || !g) return fail(VX_ERR_INVALID_ARG, "null argument");
+    VX_TRY(check_voxel_size(vs));
+    vx_mesh* mesh = const_cast<vx_mesh*>(mesh_c);
+    VX_TRY(need_device(g->device));
+    if (mesh->device != g->device) return fail(VX_ERR_INVALID_ARG, "mesh and grid live on different devices");
+    DeviceGuard dg(g->device);
+    VX_TRY(mesh_to_device(mesh));
+    vx_voxelize_opts o{};
+    if (opts) o = *opts;
+    g->stream = (hipStream_t)o.stream;
+    hipStream_t s = g->stream;
+    if (o.sat_variant != 0 && o.sat_variant != 1) return fail(VX_ERR_INVALID_ARG, "sat_variant must be 0 or 1");
+
+    VX_HIP(g->small.ensure(sizeof(Small)));
+    Small* ds = g->small.as<Small>();
+    Extent ex;
+    VX_TRY(compute_extent(mesh, vs, ds, s, &ex));
+    const uint64_t nvox = ex.dim[0] * ex.dim[1] * ex.dim[2];
+    if (nvox > kMaxVoxels) return fail(VX_ERR_CAPACITY, "grid exceeds 2^37 voxels");
+    fill_params(g->g, ex.mn, vs, ex.dim);
+    for (int a = 0; a < 3; ++a) { g->bbmin[a] = ex.mn[a]; g->bbmax[a] = ex.mx[a]; g->bbc[a] = ex.ctr[a]; }
+    VX_TRY(init_grid_storage(g));
+
+    uint64_t tb = 0, te = mesh->nt;
+    if (o.tri_begin || o.tri_end) {
+        if (o.tri_begin > o.tri_end || o.tri_end > mesh->nt) return fail(VX_ERR_INVALID_ARG, "triangle shard out of range");
+        tb = o.tri_begin;
+        te = o.tri_end;
+    }
+    uint64_t wb = 0, we = g->g.nwords;
+    if (o.word_begin || o.word_end) {
+        if (o.word_begin > o.word_end || o.word_end > g->g.nwords) return fail(VX_ERR_INVALID_ARG, "word shard out of range");
+        wb = o.word_begin;
+        we = o.word_end;
+    }
+    g->triangles = te - tb;
+    const uint32_t ntri = (uint32_t)(te - tb);
+    if (ntri == 0 || nvox == 0 || wb == we) return VX_OK;
+
+    // z slab that contains the voxels of words [wb, we)
+    const uint64_t XY = ex.dim[0] * ex.dim[1];
+    uint32_t zlo = (uint32_t)((wb * 32) / XY);
+    uint64_t zh = (we * 32 + XY - 1) / XY;
+    if (zh > ex.dim[2]) zh = ex.dim[2];
+    const uint32_t zhi = (uint32_t)zh;
+
+    uint64_t U = 0;
+    VX_TRY(run_setup(mesh, g->g, o.sat_variant, tb, ntri, zlo, zhi, g->recs, g->units, g->ubase, g->scantmp, ds, s, &U));
+    if (U == 0) return VX_OK;
+    uint32_t* umask = nullptr;
+    if (g->kind == VX_GRID_VEC) {
+        VX_HIP(g->umask.ensure((size_t)(U + 1) * 4));
+        umask = g->umask.as<uint32_t>();
+    }
+    vx::launch_voxelize(g->recs.as<vx::TriRec>(), g->ubase.as<uint32_t>(), ntri, g->g, o.sat_variant, zlo, g->words.as<uint32_t>(), wb, we, umask,
+                        &ds->set_calls, s);
+    g->counts_valid = false;
+    if (g->kind == VX_GRID_VEC) {
+        // VoxelGridVec::setVoxel appends one Aabb per call (voxelgridVecEncoding.cpp:19-39): ordered emission
+        VX_HIP(g->hbase.ensure((size_t)(U + 2) * 4));
+        VX_HIP(g->scantmp.ensure(vx::scan_tmp_bytes(U)));
+        vx::launch_scan_u32(umask, g->hbase.as<uint32_t>(), U, true, g->scantmp.p, &ds->total_b, s);
+        unsigned long long hits = 0;
+        VX_HIP(hipMemcpyAsync(&hits, &ds->total_b, 8, hipMemcpyDeviceToHost, s));
+        VX_HIP(hipStreamSynchronize(s));
+        if (hits >= 0xFFFFFFFFull) return fail(VX_ERR_CAPACITY, "more than 2^32 voxel hits");
+        VX_HIP(g->vec.ensure((size_t)(hits + 1) * sizeof(vx_aabb)));
+        vx::launch_emit_units(g->recs.as<vx::TriRec>(), g->ubase.as<uint32_t>(), ntri, g->g, zlo, umask, g->hbase.as<uint32_t>(),
+                              g->vec.as<vx_aabb>(), nullptr, s);
+        g->vec_count = hits;
+    }
+    VX_HIP(hipGetLastError());
+    return VX_OK;
+}
+
+vx_status vx_voxelize(const vx_mesh* mesh, float vs, vx_grid_kind kind, const vx_voxelize_opts* opts, vx_grid** out)
+{
+    if (!mesh || !out) return fail(VX_ERR_INVALID_ARG, "null argument");
+    if (kind != VX_GRID_BOOL && kind != VX_GRID_AABBSTRUCT && kind != VX_GRID_VEC) return fail(VX_ERR_INVALID_ARG, "unknown grid kind");
+    vx_grid* g = new vx_grid();
+    g->kind = kind;
+    g->set_dev(mesh->device);
+    const vx_status s = vx_voxelize_into(mesh, vs, opts, g);
+    if (s != VX_OK) {
+        g->release_all();
+        delete g;
+        return s;
+    }
+    *out = g;
+    return VX_OK;
+}
+
+// ---- grid -----------------------------------------------------------------------------------------------------
+vx_status vx_grid_create(vx_grid_kind kind, uint64_t x, uint64_t y, uint64_t z, float vs, const float origin[3], void* stream, vx_grid** out)
+{
+    if (!out) return fail(VX_ERR_INVALID_ARG, "null argument");
+    if (kind != VX_GRID_BOOL && kind != VX_GRID_AABBSTRUCT && kind != VX_GRID_VEC) return fail(VX_ERR_INVALID_ARG, "unknown grid kind");
+    if (x > 65535 || y > 65535 || z > 65535 || x * y * z > kMaxVoxels) return fail(VX_ERR_CAPACITY, "grid too large");
+    VX_TRY(need_device(g_device));
+    vx_grid* g = new vx_grid();
+    g->kind = kind;
+    g->set_dev(g_device);
+    g->stream = (hipStream_t)stream;
+    const float zero[3] = {0.f, 0.f, 0.f};
+    const uint64_t dim[3] = {x, y, z};
+    fill_params(g->g, origin ? origin : zero, vs, dim);
+    DeviceGuard dg(g->device);
+    const vx_status s = init_grid_storage(g);
+    if (s != VX_OK) { g->release_all(); delete g; return s; }
+    *out = g;
+    return VX_OK;
+}
+
+vx_status vx_grid_describe(const vx_grid* gc, vx_grid_desc* d)
+{
+    if (!gc || !d) return fail(VX_ERR_INVALID_ARG, "null argument");
+    vx_grid* g = const_cast<vx_grid*>(gc);
+    VX_TRY(sync_counts(g));
+    VX_TRY(ensure_prefix(g));
+    std::memset(d, 0, sizeof(*d));
+    for (int a = 0; a < 3; ++a) {
+        d->dim[a] = g->g.dim[a];
+        d->origin[a] = g->g.org[a];
+        d->bbox_min[a] = g->bbmin[a];
+        d->bbox_max[a] = g->bbmax[a];
+        d->bbox_center[a] = g->bbc[a];
+    }
+    d->voxel_size = g->g.vs;
+    d->num_words = g->g.nwords;
+    d->set_calls = g->set_calls;
+    d->occupied = g->occupied;
+    d->triangles = g->triangles;
+    d->kind = g->kind;
+    d->device = g->device;
+    return VX_OK;
+}
+
+vx_status vx_grid_set_voxel(vx_grid* g, uint64_t x, uint64_t y, uint64_t z)
+{
+    if (!g) return fail(VX_ERR_INVALID_ARG, "null argument");
+    if (x >= g->g.dim[0] || y >= g->g.dim[1] || z >= g->g.dim[2]) return fail(VX_ERR_OUT_OF_BOUNDS, "Index out of bounds");
+    DeviceGuard dg(g->device);
+    const uint64_t i = x + (uint64_t)g->g.dim[0] * (y + (uint64_t)g->g.dim[1] * z);
+    vx::launch_set_bit(g->words.as<uint32_t>(), i, g->stream);
+    if (g->kind == VX_GRID_VEC) {
+        // append {c - half, c + half} (voxelgridVecEncoding.cpp:27-36); the float recipe is shared with the kernels
+        vx_aabb b;
+        vx::cell_aabb(g->g, (uint32_t)x, (uint32_t)y, (uint32_t)z, b.minimum);
+        const size_t need = (size_t)(g->vec_count + 1) * sizeof(vx_aabb);
+        if (need > g->vec.cap) {
+            DevBuf nb;
+            nb.dev = g->device;
+            VX_HIP(nb.ensure(need * 2));
+            if (g->vec_count) VX_HIP(hipMemcpyAsync(nb.p, g->vec.p, (size_t)g->vec_count * sizeof(vx_aabb), hipMemcpyDeviceToDevice, g->stream));
+            VX_HIP(hipStreamSynchronize(g->stream));
+            g->vec.release();
+            g->vec = nb;
+        }
+        VX_HIP(hipMemcpyAsync(g->vec.as<vx_aabb>() + g->vec_count, &b, sizeof(b), hipMemcpyHostToDevice, g->stream));
+        VX_HIP(hipStreamSynchronize(g->stream));
+        g->vec_count++;
+    }
+    g->host_set_calls++;
+    g->set_calls++;
+    g->coarse_valid = g->prefix_valid = false;
+    return VX_OK;
+}
+
+vx_status vx_grid_test_voxel(const vx_grid* g, uint64_t x, uint64_t y, uint64_t z, int* occ)
+{
+    if (!g || !occ) return fail(VX_ERR_INVALID_ARG, "null argument");
+    if (x >= g->g.dim[0] || y >= g->g.dim[1] || z >= g->g.dim[2]) return fail(VX_ERR_OUT_OF_BOUNDS, "Index out of bounds");
+    DeviceGuard dg(g->device);
+    const uint64_t i = x + (uint64_t)g->g.dim[0] * (y + (uint64_t)g->g.dim[1] * z);
+    uint32_t w = 0;
+    VX_HIP(hipMemcpyAsync(&w, g->words.as<uint32_t>() + (i >> 5), 4, hipMemcpyDeviceToHost, g->stream));
+    VX_HIP(hipStreamSynchronize(g->stream));
+    *occ = (int)((w >> (i & 31)) & 1u);
+    return VX_OK;
+}
+
+vx_status vx_grid_coords(const vx_grid* g, uint64_t x, uint64_t y, uint64_t z, float out[3])
+{
+    if (!g || !out) return fail(VX_ERR_INVALID_ARG, "null argument");
+    if (x >= g->g.dim[0] || y >= g->g.dim[1] || z >= g->g.dim[2]) return fail(VX_ERR_OUT_OF_BOUNDS, "Index out of bounds");  // voxelgrid.hpp:93-95
+    out[0] = vx::cell_centre(g->g.org[0], g->g.vs, (uint32_t)x);
+    out[1] = vx::cell_centre(g->g.org[1], g->g.vs, (uint32_t)y);
+    out[2] = vx::cell_centre(g->g.org[2], g->g.vs, (uint32_t)z);
+    return VX_OK;
+}
+
+uint64_t vx_grid_bytes(const vx_grid* gc)
+{
+    if (!gc) return 0;
+    vx_grid* g = const_cast<vx_grid*>(gc);
+    switch (g->kind) {
+        case VX_GRID_BOOL: return g->g.nwords * 4;     // m_voxel.size() * sizeof(unsigned)
+        case VX_GRID_AABBSTRUCT: return g->g.nvox * 28;  // sizeof(AabbInternal) == 28
+        case VX_GRID_VEC: return g->vec_count * 24;      // one Aabb per setVoxel call
+    }
+    return 0;
+}
+
+vx_status vx_grid_bitmask(const vx_grid* g, uint32_t* host_words, uint64_t cap)
+{
+    if (!g || (!host_words && cap)) return fail(VX_ERR_INVALID_ARG, "null argument");
+    if (cap < g->g.nwords) return fail(VX_ERR_CAPACITY, "bitmask buffer too small");
+    DeviceGuard dg(g->device);
+    if (g->g.nwords) VX_HIP(hipMemcpyAsync(host_words, g->words.p, (size_t)g->g.nwords * 4, hipMemcpyDeviceToHost, g->stream));
+    VX_HIP(hipStreamSynchronize(g->stream));
+    return VX_OK;
+}
+
+const uint32_t* vx_grid_bitmask_device(const vx_grid* g) { return g ? g->words.as<uint32_t>() : nullptr; }
+uint32_t* vx_grid_bitmask_device_mut(vx_grid* g)
+{
+    if (!g) return nullptr;
+    g->coarse_valid = g->prefix_valid = false;
+    return g->words.as<uint32_t>();
+}
+vx_status vx_grid_refresh(vx_grid* g)
+{
+    if (!g) return fail(VX_ERR_INVALID_ARG, "null argument");
+    g->coarse_valid = g->prefix_valid = false;
+    VX_TRY(ensure_prefix(g));
+    return ensure_coarse(g);
+}
+
+vx_status vx_grid_aabbs_device(const vx_grid* gc, vx_aabb* dev_out, uint64_t cap, uint64_t* count)
+{
+    if (!gc) return fail(VX_ERR_INVALID_ARG, "null argument");
+    vx_grid* g = const_cast<vx_grid*>(gc);
+    DeviceGuard dg(g->device);
+    if (g->kind == VX_GRID_VEC) {
+        if (count) *count = g->vec_count;
+        const uint64_t n = cap < g->vec_count ? cap : g->vec_count;
+        if (n && dev_out) VX_HIP(hipMemcpyAsync(dev_out, g->vec.p, (size_t)n * sizeof(vx_aabb), hipMemcpyDeviceToDevice, g->stream));
+        return VX_OK;
+    }
+    VX_TRY(ensure_prefix(g));
+    if (count) *count = g->occupied;
+    if (cap && dev_out && g->occupied)
+        vx::launch_emit_bool_aabbs(g->words.as<uint32_t>(), g->wprefix.as<uint32_t>(), g->g, dev_out, cap, g->stream);
+    VX_HIP(hipGetLastError());
+    return VX_OK;
+}
+
+vx_status vx_grid_aabbs(const vx_grid* gc, vx_aabb* host_out, uint64_t cap, uint64_t* count)
+{
+    if (!gc) return fail(VX_ERR_INVALID_ARG, "null argument");
+    vx_grid* g = const_cast<vx_grid*>(gc);
+    DeviceGuard dg(g->device);
+    uint64_t n = 0;
+    if (g->kind == VX_GRID_VEC) n = g->vec_count;
+    else { VX_TRY(ensure_prefix(g)); n = g->occupied; }
+    if (count) *count = n;
+    const uint64_t m = cap < n ? cap : n;
+    if (!m || !host_out) return VX_OK;
+    if (g->kind == VX_GRID_VEC) {
+        VX_HIP(hipMemcpyAsync(host_out, g->vec.p, (size_t)m * sizeof(vx_aabb), hipMemcpyDeviceToHost, g->stream));
+        VX_HIP(hipStreamSynchronize(g->stream));
+        return VX_OK;
+    }
+    DevBuf tmp;
+    tmp.dev = g->device;
+    VX_HIP(tmp.ensure((size_t)m * sizeof(vx_aabb)));
+    vx::launch_emit_bool_aabbs(g->words.as<uint32_t>(), g->wprefix.as<uint32_t>(), g->g, tmp.as<vx_aabb>(), m, g->stream);
+    hipError_t e = hipMemcpyAsync(host_out, tmp.p, (size_t)m * sizeof(vx_aabb), hipMemcpyDeviceToHost, g->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+    tmp.release();
+    VX_HIP(e);
+    return VX_OK;
+}
+
+void vx_grid_free(vx_grid* g)
+{
+    if (!g) return;
+    if (g->stream || true) { DeviceGuard dg(g->device); (void)hipStreamSynchronize(g->stream); }
+    g->release_all();
+    delete g;
+}
+
+// ---- rays -----------------------------------------------------------------------------------------------------
+static vx_status trace_common(vx_grid* g, const float* dev_rays, const vx::Camera* cam, uint64_t nrays, float tmin, float tmax, float* dev_t,
+                              uint32_t* dev_prim, vx_hit* dev_hits, uint64_t* dev_nhits)
+{
+    VX_TRY(ensure_coarse(g));
+    const uint32_t* prefix = nullptr;
+    if (dev_prim || dev_hits) { VX_TRY(ensure_prefix(g)); prefix = g->wprefix.as<uint32_t>(); }
+    vx::launch_trace(g->g, g->cdim, g->words.as<uint32_t>(), g->cwords.as<uint32_t>(), prefix, dev_rays, cam, nrays, tmin, tmax, dev_t, dev_prim,
+                     dev_hits, (unsigned long long*)dev_nhits, g->stream);
+    VX_HIP(hipGetLastError());
+    return VX_OK;
+}
+
+vx_status vx_trace_device(const vx_grid* gc, const float* dev_rays, uint64_t nrays, float tmin, float tmax, float* dev_t, uint32_t* dev_prim,
+                          vx_hit* dev_hits, uint64_t* dev_nhits)
+{
+    if (!gc || (nrays && !dev_rays)) return fail(VX_ERR_INVALID_ARG, "null argument");
+    if (dev_hits && !dev_nhits) return fail(VX_ERR_INVALID_ARG, "dev_hits needs dev_num_hits");
+    vx_grid* g = const_cast<vx_grid*>(gc);
+    DeviceGuard dg(g->device);
+    return trace_common(g, dev_rays, nullptr, nrays, tmin, tmax, dev_t, dev_prim, dev_hits, dev_nhits);
+}
+
+vx_status vx_trace_primary_device(const vx_grid* gc, const float vi[16], const float pi[16], uint32_t w, uint32_t h, float tmin, float tmax,
+                                  float* dev_t, uint32_t* dev_prim)
+{
+    if (!gc || !vi || !pi || !dev_t) return fail(VX_ERR_INVALID_ARG, "null argument");
+    vx_grid* g = const_cast<vx_grid*>(gc);
+    DeviceGuard dg(g->device);
+    vx::Camera cam;
+    std::memcpy(cam.viewInv, vi, 64);
+    std::memcpy(cam.projInv, pi, 64);
+    cam.width = w;
+    cam.height = h;
+    return trace_common(g, nullptr, &cam, (uint64_t)w * h, tmin, tmax, dev_t, dev_prim, nullptr, nullptr);
+}
+
+vx_status vx_trace(const vx_grid* gc, const float* host_rays, uint64_t nrays, float tmin, float tmax, float* host_t, uint32_t* host_prim,
+                   uint64_t* num_hits)
+{
+    if (!gc || (nrays && !host_rays)) return fail(VX_ERR_INVALID_ARG, "null argument");
+    vx_grid* g = const_cast<vx_grid*>(gc);
+    DeviceGuard dg(g->device);
+    if (num_hits) *num_hits = 0;
+    if (!nrays) return VX_OK;
+    DevBuf dr, dt, dp;
+    dr.dev = dt.dev = dp.dev = g->device;
+    vx_status st = VX_OK;
+    hipError_t e = dr.ensure((size_t)nrays * 24);
+    if (e == hipSuccess) e = dt.ensure((size_t)nrays * 4);
+    if (e == hipSuccess && host_prim) e = dp.ensure((size_t)nrays * 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(dr.p, host_rays, (size_t)nrays * 24, hipMemcpyHostToDevice, g->stream);
+    if (e == hipSuccess) {
+        st = trace_common(g, dr.as<float>(), nullptr, nrays, tmin, tmax, dt.as<float>(), host_prim ? dp.as<uint32_t>() : nullptr, nullptr, nullptr);
+        if (st == VX_OK) {
+            std::vector<float> tbuf;
+            float* tdst = host_t;
+            if (!tdst) { tbuf.resize(nrays); tdst = tbuf.data(); }
+            e = hipMemcpyAsync(tdst, dt.p, (size_t)nrays * 4, hipMemcpyDeviceToHost, g->stream);
+            if (e == hipSuccess && host_prim) e = hipMemcpyAsync(host_prim, dp.p, (size_t)nrays * 4, hipMemcpyDeviceToHost, g->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+            if (e == hipSuccess && num_hits) {
+                uint64_t n = 0;
+                for (uint64_t i = 0; i < nrays; ++i) n += tdst[i] > 0.0f;
+                *num_hits = n;
+            }
+        }
+    }
+    dr.release(); dt.release(); dp.release();
+    if (st != VX_OK) return st;
+    VX_HIP(e);
+    return VX_OK;
+}
+
+// ---- octree ---------------------------------------------------------------------------------------------------
+static uint32_t build_node_host(vx_octree* o, const uint64_t* items, uint32_t begin, uint32_t end, uint32_t depth)
+{
+    // octTree.hpp:319-358 (node numbering is pre-order; children hold indices into the node array)
+    const uint32_t ni = (uint32_t)o->nodes.size();
+    o->nodes.emplace_back();
+    o->nodes[ni].start = begin;
+    o->nodes[ni].count = end - begin;
+    for (int c = 0; c < 8; ++c) o->nodes[ni].children[c] = 0xFFFFFFFFu;
+    if (depth >= o->bits || (uint64_t)(end - begin) <= o->max_items) return ni;
+    const uint32_t shift = 3 * (o->bits - 1 - depth);
+    uint32_t cur = begin;
+    for (int child = 0; child < 8; ++child) {
+        if (cur >= end) break;
+        const uint32_t cb = cur;
+        while (cur < end && (int)((items[cur] >> shift) & 7u) == child) ++cur;
+        if (cb == cur) continue;
+        const uint32_t ci = build_node_host(o, items, cb, cur, depth + 1);
+        o->nodes[ni].children[child] = ci;
+    }
+    return ni;
+}
+
+vx_status vx_octree_build(const vx_mesh* mesh_c, float vs, uint64_t max_items, void* stream, vx_octree** out)
+{
+    if (!mesh_c || !out) return fail(VX_ERR_INVALID_ARG, "null argument");
+    VX_TRY(check_voxel_size(vs));
+    vx_mesh* mesh = const_cast<vx_mesh*>(mesh_c);
+    VX_TRY(need_device(mesh->device));
+    DeviceGuard dg(mesh->device);
+    VX_TRY(mesh_to_device(mesh));
+    hipStream_t s = (hipStream_t)stream;
+    vx_octree* o = new vx_octree();
+    o->device = mesh->device;
+    o->stream = s;
+    o->vs = vs;
+    o->max_items = max_items;
+    o->items.dev = o->device;
+    DevBuf small, recs, units, ubase, scantmp, umask, hbase, unsorted, sorttmp;
+    for (DevBuf* b : {&small, &recs, &units, &ubase, &scantmp, &umask, &hbase, &unsorted, &sorttmp}) b->dev = o->device;
+    auto cleanup = [&]() { for (DevBuf* b : {&small, &recs, &units, &ubase, &scantmp, &umask, &hbase, &unsorted, &sorttmp}) b->release(); };
+    auto bail = [&](vx_status st) { cleanup(); o->items.release(); delete o; return st; };
+#define OCT_HIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return bail(fail(VX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__))); } while (0)
+#define OCT_TRY(expr) do { vx_status s__ = (expr); if (s__ != VX_OK) return bail(s__); } while (0)
+    OCT_HIP(small.ensure(sizeof(Small)));
+    Small* ds = small.as<Small>();
+    Extent ex;
+    OCT_TRY(compute_extent(mesh, vs, ds, s, &ex));
+    for (int a = 0; a < 3; ++a) { o->root_min[a] = ex.mn[a]; o->root_max[a] = ex.mx[a]; o->dim[a] = ex.dim[a]; }
+    uint64_t maxDim = ex.dim[0] > ex.dim[1] ? ex.dim[0] : ex.dim[1];
+    if (ex.dim[2] > maxDim) maxDim = ex.dim[2];
+    if (maxDim == 0) { cleanup(); *out = o; return VX_OK; }  // octTree.hpp:571-574
+    o->bits = (uint32_t)std::ceil(std::log2((double)maxDim));  // :577-578
+    if (o->bits > 21) return bail(fail(VX_ERR_MORTON_BITS, "We support up to 21 bits per axis (max 2^21 voxels per dimension)!"));
+    const float ext = vs * (float)(1u << o->bits);  // :592
+    for (int a = 0; a < 3; ++a) o->root_max[a] = ex.mn[a] + ext;
+    const uint32_t ntri = (uint32_t)mesh->nt;
+    if (ntri == 0) { cleanup(); *out = o; return VX_OK; }  // :696-699 (returns before buildTree)
+    vx::GridParams g;
+    fill_params(g, ex.mn, vs, ex.dim);
+    uint64_t U = 0;
+    OCT_TRY(run_setup(mesh, g, /*sat a7: octTree.hpp:762*/ 0, 0, ntri, 0, (uint32_t)ex.dim[2], recs, units, ubase, scantmp, ds, s, &U));
+    unsigned long long hits = 0;
+    if (U) {
+        OCT_HIP(umask.ensure((size_t)(U + 1) * 4));
+        OCT_HIP(hbase.ensure((size_t)(U + 2) * 4));
+        OCT_HIP(scantmp.ensure(vx::scan_tmp_bytes(U)));
+        OCT_HIP(hipMemsetAsync(&ds->set_calls, 0, 8, s));
+        vx::launch_voxelize(recs.as<vx::TriRec>(), ubase.as<uint32_t>(), ntri, g, 0, 0, nullptr, 0, 0, umask.as<uint32_t>(), &ds->set_calls, s);
+        vx::launch_scan_u32(umask.as<uint32_t>(), hbase.as<uint32_t>(), U, true, scantmp.p, &ds->total_b, s);
+        OCT_HIP(hipMemcpyAsync(&hits, &ds->total_b, 8, hipMemcpyDeviceToHost, s));
+        OCT_HIP(hipStreamSynchronize(s));
+        if (hits >= 0xFFFFFFFFull) return bail(fail(VX_ERR_CAPACITY, "more than 2^32 octree items"));
+    }
+    o->nitems = hits;
+    std::vector<uint64_t> host_items((size_t)hits);
+    if (hits) {
+        OCT_HIP(unsorted.ensure((size_t)hits * 8));
+        OCT_HIP(o->items.ensure((size_t)hits * 8));
+        vx::launch_emit_units(recs.as<vx::TriRec>(), ubase.as<uint32_t>(), ntri, g, 0, umask.as<uint32_t>(), hbase.as<uint32_t>(), nullptr,
+                              unsorted.as<uint64_t>(), s);
+        const size_t tb = vx::sort_tmp_bytes(hits);
+        OCT_HIP(sorttmp.ensure(tb));
+        vx::launch_sort_u64(unsorted.as<uint64_t>(), o->items.as<uint64_t>(), hits, (int)(3 * o->bits ? 3 * o->bits : 1), sorttmp.p, tb, s);
+        OCT_HIP(hipMemcpyAsync(host_items.data(), o->items.p, (size_t)hits * 8, hipMemcpyDeviceToHost, s));
+        OCT_HIP(hipStreamSynchronize(s));
+    }
+    // node array (pre-order DFS).  TODO(next): device-parallel construction from segment boundaries per depth.
+    o->nodes.reserve(std::max<size_t>(1, (size_t)hits / 4));
+    build_node_host(o, host_items.data(), 0, (uint32_t)hits, 0);
+    o->built_tree = true;
+    cleanup();
+#undef OCT_HIP
+#undef OCT_TRY
+    *out = o;
+    return VX_OK;
+}
+
+uint64_t vx_octree_num_items(const vx_octree* o) { return o ? o->nitems : 0; }
+uint64_t vx_octree_num_nodes(const vx_octree* o) { return o ? o->nodes.size() : 0; }
+uint64_t vx_octree_bytes(const vx_octree* o) { return o ? o->nitems * 8 + (uint64_t)o->nodes.size() * 40 : 0; }
+
+vx_status vx_octree_items(const vx_octree* o, uint64_t* host, uint64_t cap)
+{
+    if (!o || (!host && cap)) return fail(VX_ERR_INVALID_ARG, "null argument");
+    if (cap < o->nitems) return fail(VX_ERR_CAPACITY, "item buffer too small");
+    if (!o->nitems) return VX_OK;
+    DeviceGuard dg(o->device);
+    VX_HIP(hipMemcpyAsync(host, o->items.p, (size_t)o->nitems * 8, hipMemcpyDeviceToHost, o->stream));
+    VX_HIP(hipStreamSynchronize(o->stream));
+    return VX_OK;
+}
+
+vx_status vx_octree_nodes(const vx_octree* o, vx_octree_node* host, uint64_t cap)
+{
+    if (!o || (!host && cap)) return fail(VX_ERR_INVALID_ARG, "null argument");
+    if (cap < o->nodes.size()) return fail(VX_ERR_CAPACITY, "node buffer too small");
+    if (!o->nodes.empty()) std::memcpy(host, o->nodes.data(), o->nodes.size() * sizeof(vx_octree_node));
+    return VX_OK;
+}
+
+vx_status vx_octree_root_bounds(const vx_octree* o, float mn[3], float mx[3])
+{
+    if (!o || !mn || !mx) return fail(VX_ERR_INVALID_ARG, "null argument");
+    std::memcpy(mn, o->root_min, 12);
+    std::memcpy(mx, o->root_max, 12);
+    return VX_OK;
+}
+
+vx_status vx_octree_aabbs_device(const vx_octree* o, vx_aabb* dev_out, uint64_t cap, uint64_t* count)
+{
+    if (!o) return fail(VX_ERR_INVALID_ARG, "null argument");
+    const uint64_t n = o->nodes.empty() ? 0 : o->nitems;  // octTree.hpp:505-507
+    if (count) *count = n;
+    const uint64_t m = cap < n ? cap : n;
+    if (!m || !dev_out) return VX_OK;
+    DeviceGuard dg(o->device);
+    vx::launch_emit_morton_aabbs(o->items.as<uint64_t>(), m, o->root_min, o->vs, dev_out, o->stream);
+    VX_HIP(hipGetLastError());
+    return VX_OK;
+}
+
+vx_status vx_octree_aabbs(const vx_octree* o, vx_aabb* host_out, uint64_t cap, uint64_t* count)
+{
+    if (!o) return fail(VX_ERR_INVALID_ARG, "null argument");
+    const uint64_t n = o->nodes.empty() ? 0 : o->nitems;
+    if (count) *count = n;
+    const uint64_t m = cap < n ? cap : n;
+    if (!m || !host_out) return VX_OK;
+    DeviceGuard dg(o->device);
+    DevBuf tmp;
+    tmp.dev = o->device;
+    VX_HIP(tmp.ensure((size_t)m * sizeof(vx_aabb)));
+    vx::launch_emit_morton_aabbs(o->items.as<uint64_t>(), m, o->root_min, o->vs, tmp.as<vx_aabb>(), o->stream);
+    hipError_t e = hipMemcpyAsync(host_out, tmp.p, (size_t)m * sizeof(vx_aabb), hipMemcpyDeviceToHost, o->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(o->stream);
+    tmp.release();
+    VX_HIP(e);
+    return VX_OK;
+}
+
+void vx_octree_free(vx_octree* o)
+{
+    if (!o) return;
+    o->items.release();
+    delete o;
+}
+
+// ---- sharding helpers -----------------------------------------------------------------------------------------
+void vx_shard_words(uint64_t num_words, int rank, int world, uint64_t* wb, uint64_t* we, uint64_t* padded)
+{
+    if (world < 1) world = 1;
+    const uint64_t chunk = (num_words + (uint64_t)world - 1) / (uint64_t)world;
+    uint64_t b = (uint64_t)rank * chunk;
+    if (b > num_words) b = num_words;
+    uint64_t e = b + chunk;
+    if (e > num_words) e = num_words;
+    if (wb) *wb = b;
+    if (we) *we = e;
+    if (padded) *padded = chunk;
+}
+
+void vx_shard_range(uint64_t count, int rank, int world, uint64_t* begin, uint64_t* end)
+{
+    if (world < 1) world = 1;
+    const uint64_t chunk = (count + (uint64_t)world - 1) / (uint64_t)world;
+    uint64_t b = (uint64_t)rank * chunk;
+    if (b > count) b = count;
+    uint64_t e = b + chunk;
+    if (e > count) e = count;
+    if (begin) *begin = b;
+    if (end) *end = e;
+}
+
+}  // extern "C"

@@ -1,0 +1,72 @@
+// vx_internal.h -- launch interface between the C ABI (vx_api.cpp) and the gfx950 kernels (vx_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "vx_math.h"
+#include "../../include/voxhip.h"
+
+namespace vx {
+
+// De-indexed triangle + its candidate voxel box, written once by k_tri_setup and read by every later pass.
+// 48 B, 16-B aligned: three dwordx4 loads.
+struct __attribute__((aligned(16))) TriRec {
+    float v[9];     // v0.xyz v1.xyz v2.xyz                      loadPos, VoxelBuilder.hpp:356-362
+    uint32_t xr;    // start | count << 16 along x               candidate range, VoxelBuilder.hpp:175-184
+    uint32_t yr;
+    uint32_t zr;
+};
+static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
+
+constexpr uint32_t kCoarse = 8;        // fine cells per coarse cell edge (ray traversal mip)
+constexpr uint32_t kCoarseShift = 3;
+constexpr int kScanBlock = 256;
+constexpr int kScanItems = 8;          // elements per thread in the scan kernels
+constexpr int kScanTile = kScanBlock * kScanItems;
+
+struct Camera { float viewInv[16]; float projInv[16]; uint32_t width, height; };
+
+// ---- launchers (all asynchronous on `s`) ------------------------------------------------------------------
+// K1: bbox of all vertices with the reference's first-occurrence tie rule; out6 = min xyz, max xyz (device).
+void launch_bbox(const float* verts, uint64_t nverts, unsigned long long* keys6, float* out6, hipStream_t s);
+
+// K2a: per-triangle record + number of row-segment work units; zlo/zhi clamp the candidate box to a z slab.
+void launch_tri_setup(const float* verts, const int32_t* idx, uint64_t tri_begin, uint32_t ntri, const GridParams& g,
+                      int sat_variant, uint32_t zlo, uint32_t zhi, TriRec* recs, uint32_t* units, hipStream_t s);
+
+// exclusive scan of n uint32 (or of their popcounts) into out[0..n] (out[n] = total, saturating check via *total64)
+size_t scan_tmp_bytes(uint64_t n);
+void launch_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, bool popcount_input, void* tmp,
+                     unsigned long long* total64, hipStream_t s);
+
+// K2: triangle/voxel overlap over all work units; ORs hits into `words` (only words in [wb,we)), optionally
+// stores each unit's 32-bit hit mask (unit_mask) for the ordered emitters; adds the hit count to *set_calls.
+void launch_voxelize(const TriRec* recs, const uint32_t* unit_base, uint32_t ntri, const GridParams& g, int sat_variant,
+                     uint32_t zlo, uint32_t* words, uint64_t wb, uint64_t we, uint32_t* unit_mask,
+                     unsigned long long* set_calls, hipStream_t s);
+
+// K3: VoxelGridVec / Octree emitters: one output per set bit of unit_mask, in unit order (== reference order).
+void launch_emit_units(const TriRec* recs, const uint32_t* unit_base, uint32_t ntri, const GridParams& g, uint32_t zlo,
+                       const uint32_t* unit_mask, const uint32_t* hit_base, vx_aabb* aabbs, uint64_t* morton, hipStream_t s);
+
+// K4: bitmask -> ordered AABB list (word_prefix = exclusive scan of popcounts, nwords+1 entries)
+void launch_emit_bool_aabbs(const uint32_t* words, const uint32_t* word_prefix, const GridParams& g, vx_aabb* out,
+                            uint64_t capacity, hipStream_t s);
+// AABBs from sorted Morton items (Octree::getAabbs)
+void launch_emit_morton_aabbs(const uint64_t* items, uint64_t n, const float root_min[3], float vs, vx_aabb* out, hipStream_t s);
+
+// coarse occupancy mip for the ray kernel
+void launch_build_coarse(const uint32_t* words, const GridParams& g, const uint32_t cdim[3], uint32_t* cwords, hipStream_t s);
+
+// K6: first hit per ray
+void launch_trace(const GridParams& g, const uint32_t cdim[3], const uint32_t* words, const uint32_t* cwords,
+                  const uint32_t* word_prefix, const float* rays, const Camera* cam, uint64_t nrays, float tmin, float tmax,
+                  float* t_out, uint32_t* prim_out, vx_hit* hits, unsigned long long* nhits, hipStream_t s);
+
+// single-voxel helpers
+void launch_set_bit(uint32_t* words, uint64_t idx, hipStream_t s);
+
+// device radix sort of uint64 keys (octree items); tmp sized by sort_tmp_bytes
+size_t sort_tmp_bytes(uint64_t n);
+void launch_sort_u64(uint64_t* keys_in, uint64_t* keys_out, uint64_t n, int bits, void* tmp, size_t tmp_bytes, hipStream_t s);
+
+}  // namespace vx

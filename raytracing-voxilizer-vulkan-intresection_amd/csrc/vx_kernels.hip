@@ -1,0 +1,792 @@
+// vx_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the voxelizer / ray hot path.
+//
+//   K1  k_bbox            vertex min/max with the reference's first-occurrence tie rule   (VoxelBuilder.hpp:198-224)
+//   K2a k_tri_setup       de-index triangles, candidate voxel box, work-unit count        (VoxelBuilder.hpp:356-362,170-184)
+//   K2  k_voxelize        13-axis SAT per (triangle, y, z, 32-voxel x segment) work unit,
+//                         hit bits OR-ed into the occupancy bitmask                       (VoxelBuilder.hpp:118-162/226-335,186-195)
+//   K3  k_emit_units      ordered AABB / Morton emission with duplicates (Vec, Octree)    (voxelgridVecEncoding.cpp:19-39, octTree.hpp:765)
+//   K4  k_emit_bool       bitmask -> ascending AABB list                                  (voxelgridBool.cpp:18-52)
+//   K6  k_trace           two-level conservative 3D-DDA + the rint slab formula           (shaders/raytrace.rint:46-71)
+//   scan kernels          device-wide exclusive scan (work-unit bases, popcount prefixes)
+//
+// Everything here is integer / float32 VALU and HBM/L2 traffic: no MFMA (nothing is a contraction).
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (bit-exact float semantics, see vx_math.h).
+#include "vx_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace vx {
+
+static inline unsigned grid_for(uint64_t n, unsigned block, unsigned cap)
+{
+    uint64_t b = (n + block - 1) / block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (unsigned)b;
+}
+constexpr unsigned kMaxBlocks = 256 * 8;  // 256 CUs x 8 resident 256-thread blocks: grid-stride beyond that
+
+// ------------------------------------------------------------------------------------------------------------
+// wave64 helpers
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m)
+{
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    lo = __shfl_xor(lo, m, 64);
+    hi = __shfl_xor(hi, m, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_u64(v, m);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K1  bbox.  std::min(cur, x) only replaces cur when x < cur, so the reference keeps the FIRST vertex (in index
+// order) among equal-comparing extremes; that only matters for the sign of a zero, and is reproduced by reducing
+// 64-bit keys (order-preserving float bits with -0 folded onto +0, then the vertex index) and reading the winning
+// vertex's own float back.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned ord_bits(float f)
+{
+    unsigned u = __float_as_uint(f);
+    if ((u << 1) == 0) u = 0;  // -0 -> +0: equal in the reference's comparisons
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void k_bbox(const float* __restrict__ verts, uint64_t nverts, unsigned long long* keys)
+{
+    unsigned long long mn[3] = {~0ull, ~0ull, ~0ull}, mx[3] = {0ull, 0ull, 0ull};
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nverts; i += (uint64_t)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const unsigned o = ord_bits(verts[3 * i + a]);
+            const unsigned long long kmin = ((unsigned long long)o << 32) | (unsigned)i;
+            const unsigned long long kmax = ((unsigned long long)o << 32) | (0xFFFFFFFFu - (unsigned)i);
+            mn[a] = kmin < mn[a] ? kmin : mn[a];
+            mx[a] = kmax > mx[a] ? kmax : mx[a];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const unsigned long long o1 = shfl_xor_u64(mn[a], m), o2 = shfl_xor_u64(mx[a], m);
+            mn[a] = o1 < mn[a] ? o1 : mn[a];
+            mx[a] = o2 > mx[a] ? o2 : mx[a];
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&keys[a], mn[a]);
+            atomicMax(&keys[3 + a], mx[a]);
+        }
+    }
+}
+
+__global__ void k_bbox_finish(const float* __restrict__ verts, uint64_t nverts, const unsigned long long* keys, float* out6)
+{
+    const int a = threadIdx.x;
+    if (a >= 6) return;
+    if (nverts == 0) { out6[a] = a < 3 ? INFINITY : -INFINITY; return; }
+    const unsigned low = (unsigned)keys[a];
+    const unsigned idx = a < 3 ? low : 0xFFFFFFFFu - low;
+    out6[a] = verts[3 * (uint64_t)idx + (a % 3)];
+}
+
+void launch_bbox(const float* verts, uint64_t nverts, unsigned long long* keys6, float* out6, hipStream_t s)
+{
+    static const unsigned long long init[6] = {~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull};
+    hipMemcpyAsync(keys6, init, sizeof(init), hipMemcpyHostToDevice, s);
+    if (nverts) hipLaunchKernelGGL(k_bbox, dim3(grid_for(nverts, 256, kMaxBlocks)), dim3(256), 0, s, verts, nverts, keys6);
+    hipLaunchKernelGGL(k_bbox_finish, dim3(1), dim3(64), 0, s, verts, nverts, keys6, out6);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Device-wide exclusive scan of uint32 (optionally of their popcounts): out[i] = sum_{j<i} f(in[j]) for i in [0,n].
+// Three passes: tile sums -> spine (one block) -> apply.  Sums are carried in 64 bits so the caller can detect a
+// total that does not fit the 32-bit outputs.
+// ------------------------------------------------------------------------------------------------------------
+template <bool POPC>
+__device__ __forceinline__ unsigned scan_ld(const uint32_t* __restrict__ in, uint64_t i, uint64_t n)
+{
+    if (i >= n) return 0u;
+    const unsigned v = in[i];
+    return POPC ? (unsigned)__popc(v) : v;
+}
+
+__device__ __forceinline__ unsigned block_excl_scan_256(unsigned v, unsigned* lds /*>=4*/, unsigned& block_total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) lds[wv] = inc;
+    __syncthreads();
+    unsigned base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const unsigned s = lds[w];
+        if (w < wv) base += s;
+        tot += s;
+    }
+    block_total = tot;
+    __syncthreads();
+    return base + inc - v;
+}
+
+template <bool POPC>
+__global__ __launch_bounds__(kScanBlock) void k_scan_sums(const uint32_t* __restrict__ in, uint64_t n, unsigned long long* sums)
+{
+    __shared__ unsigned long long lds[4];
+    const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
+    unsigned long long s = 0;
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) s += scan_ld<POPC>(in, base + j, n);
+    s = wave_sum_u64(s);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+}
+
+__global__ __launch_bounds__(1024) void k_scan_spine(unsigned long long* sums, uint32_t nblocks, unsigned long long* total)
+{
+    __shared__ unsigned long long wsum[16];
+    __shared__ unsigned long long carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (uint32_t base = 0; base < nblocks; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const unsigned long long v = i < nblocks ? sums[i] : 0ull;
+        unsigned long long inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            unsigned lo = (unsigned)inc, hi = (unsigned)(inc >> 32);
+            lo = __shfl_up(lo, d, 64);
+            hi = __shfl_up(hi, d, 64);
+            if (lane >= d) inc += ((unsigned long long)hi << 32) | lo;
+        }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        unsigned long long wbase = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) {
+            if (w < wv) wbase += wsum[w];
+            tot += wsum[w];
+        }
+        const unsigned long long carry = carry_s;
+        if (i < nblocks) sums[i] = carry + wbase + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total) *total = carry_s;
+}
+
+template <bool POPC>
+__global__ __launch_bounds__(kScanBlock) void k_scan_apply(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t n,
+                                                          const unsigned long long* __restrict__ sums)
+{
+    __shared__ unsigned lds[4];
+    const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
+    unsigned v[kScanItems];
+    unsigned tsum = 0;
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) { v[j] = scan_ld<POPC>(in, base + j, n); tsum += v[j]; }
+    unsigned btot;
+    unsigned pre = block_excl_scan_256(tsum, lds, btot) + (unsigned)sums[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) {
+        if (base + j <= n) out[base + j] = pre;
+        pre += v[j];
+    }
+}
+
+size_t scan_tmp_bytes(uint64_t n) { return (size_t)(((n + 1) + kScanTile - 1) / kScanTile + 1) * sizeof(unsigned long long); }
+
+void launch_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, bool popcount_input, void* tmp, unsigned long long* total64,
+                     hipStream_t s)
+{
+    const uint32_t nblocks = (uint32_t)(((n + 1) + kScanTile - 1) / kScanTile);
+    unsigned long long* sums = (unsigned long long*)tmp;
+    if (popcount_input) {
+        hipLaunchKernelGGL(k_scan_sums<true>, dim3(nblocks), dim3(kScanBlock), 0, s, in, n, sums);
+        hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, s, sums, nblocks, total64);
+        hipLaunchKernelGGL(k_scan_apply<true>, dim3(nblocks), dim3(kScanBlock), 0, s, in, out, n, sums);
+    } else {
+        hipLaunchKernelGGL(k_scan_sums<false>, dim3(nblocks), dim3(kScanBlock), 0, s, in, n, sums);
+        hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, s, sums, nblocks, total64);
+        hipLaunchKernelGGL(k_scan_apply<false>, dim3(nblocks), dim3(kScanBlock), 0, s, in, out, n, sums);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K2a  triangle setup.  One lane per triangle: gather the three vertices, compute the candidate voxel box exactly
+// as the reference does, clamp it to this rank's z slab, and count work units.  A work unit is one row of the box
+// (fixed y, z) cut at multiples of 32 in x, i.e. at most one 32-voxel stretch that maps onto <= 2 bitmask words.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tri_setup(const float* __restrict__ verts, const int32_t* __restrict__ idx, uint64_t tri_begin,
+                                                   uint32_t ntri, GridParams g, float vsize, uint32_t zlo, uint32_t zhi,
+                                                   TriRec* __restrict__ recs, uint32_t* __restrict__ units)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= ntri) return;
+    const int32_t* ip = idx + 3 * (tri_begin + t);
+    TriRec r;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const uint64_t vi = (uint64_t)(uint32_t)ip[k];
+        r.v[3 * k + 0] = verts[3 * vi + 0];
+        r.v[3 * k + 1] = verts[3 * vi + 1];
+        r.v[3 * k + 2] = verts[3 * vi + 2];
+    }
+    int xs, xe, ys, ye, zs, ze;
+    cand_axis(r.v[0], r.v[3], r.v[6], g.org[0], vsize, g.dim[0], xs, xe);
+    cand_axis(r.v[1], r.v[4], r.v[7], g.org[1], vsize, g.dim[1], ys, ye);
+    cand_axis(r.v[2], r.v[5], r.v[8], g.org[2], vsize, g.dim[2], zs, ze);
+    zs = zs > (int)zlo ? zs : (int)zlo;
+    ze = ze < (int)zhi ? ze : (int)zhi;
+    const uint32_t nx = xe > xs ? (uint32_t)(xe - xs) : 0u;
+    const uint32_t ny = ye > ys ? (uint32_t)(ye - ys) : 0u;
+    const uint32_t nz = ze > zs ? (uint32_t)(ze - zs) : 0u;
+    uint32_t u = 0;
+    if (nx && ny && nz) {
+        const uint32_t nseg = (((uint32_t)xs + nx - 1u) >> 5) - ((uint32_t)xs >> 5) + 1u;
+        const uint64_t uu = (uint64_t)nseg * ny * nz;
+        u = uu > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)uu;
+    }
+    r.xr = (uint32_t)(nx ? xs : 0) | (nx << 16);
+    r.yr = (uint32_t)(ny ? ys : 0) | (ny << 16);
+    r.zr = (uint32_t)(nz ? zs : 0) | (nz << 16);
+    recs[t] = r;
+    units[t] = u;
+}
+
+void launch_tri_setup(const float* verts, const int32_t* idx, uint64_t tri_begin, uint32_t ntri, const GridParams& g, int sat_variant,
+                      uint32_t zlo, uint32_t zhi, TriRec* recs, uint32_t* units, hipStream_t s)
+{
+    if (!ntri) return;
+    // serial driver: voxelSize = halfVoxelSize.x * 2.0f (VoxelBuilder.hpp:173); threaded driver: vSize = voxelSize (:500)
+    const float vsize = sat_variant == 0 ? g.half * 2.0f : g.vs;
+    hipLaunchKernelGGL(k_tri_setup, dim3((ntri + 255) / 256), dim3(256), 0, s, verts, idx, tri_begin, ntri, g, vsize, zlo, zhi, recs, units);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Work-unit decode shared by K2 and K3: unit u -> triangle t (largest t with unit_base[t] <= u) and the row
+// segment it covers.
+// ------------------------------------------------------------------------------------------------------------
+struct Unit {
+    uint32_t tri;
+    uint32_t x0, x1;   // voxel x range [x0, x1), inside one 32-aligned stretch
+    uint32_t xseg;     // x0 & ~31
+    uint32_t y, z;
+};
+
+__device__ __forceinline__ uint32_t find_tri(const uint32_t* __restrict__ unit_base, uint32_t ntri, uint32_t u)
+{
+    uint32_t lo = 0, hi = ntri;  // unit_base[lo] <= u < unit_base[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (unit_base[mid] <= u) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ Unit decode_unit(const TriRec& r, uint32_t tri, uint32_t rel)
+{
+    Unit w;
+    w.tri = tri;
+    const uint32_t xs = r.xr & 0xFFFFu, nx = r.xr >> 16;
+    const uint32_t ys = r.yr & 0xFFFFu, ny = r.yr >> 16;
+    const uint32_t zs = r.zr & 0xFFFFu;
+    const uint32_t seg0 = xs >> 5;
+    const uint32_t nseg = ((xs + nx - 1u) >> 5) - seg0 + 1u;
+    const uint32_t row = rel / nseg, sx = rel - row * nseg;
+    const uint32_t zz = row / ny, yy = row - zz * ny;
+    w.xseg = (seg0 + sx) << 5;
+    w.x0 = xs > w.xseg ? xs : w.xseg;
+    const uint32_t xe = xs + nx, se = w.xseg + 32u;
+    w.x1 = xe < se ? xe : se;
+    w.y = ys + yy;
+    w.z = zs + zz;
+    return w;
+}
+
+__device__ __forceinline__ TriRec load_rec(const TriRec* __restrict__ recs, uint32_t t)
+{
+    const float4* p = reinterpret_cast<const float4*>(recs + t);
+    const float4 a = p[0], b = p[1], c = p[2];
+    TriRec r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    r.v[8] = c.x;
+    r.xr = __float_as_uint(c.y); r.yr = __float_as_uint(c.z); r.zr = __float_as_uint(c.w);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K2  voxelize.  One lane per work unit.  The lane sweeps its <=32 voxels along x; everything of the SAT that does
+// not depend on x (two box axes, the three e x X axes, n.x) is evaluated once per row and can reject the whole row.
+// Hit bits are assembled in a register and leave the lane as at most two atomicOr (one when X % 32 == 0).
+// ------------------------------------------------------------------------------------------------------------
+template <bool EPS, bool STORE_MASK>
+__global__ __launch_bounds__(256) void k_voxelize(const TriRec* __restrict__ recs, const uint32_t* __restrict__ unit_base, uint32_t ntri,
+                                                  GridParams g, uint32_t* __restrict__ words, uint64_t wb, uint64_t we,
+                                                  uint32_t* __restrict__ unit_mask, unsigned long long* set_calls)
+{
+    const uint32_t U = unit_base[ntri];
+    unsigned hits = 0;
+    for (uint64_t u64 = (uint64_t)blockIdx.x * 256u + threadIdx.x; u64 < U; u64 += (uint64_t)gridDim.x * 256u) {
+        const uint32_t u = (uint32_t)u64;
+        const uint32_t t = find_tri(unit_base, ntri, u);
+        const TriRec r = load_rec(recs, t);
+        const Unit w = decode_unit(r, t, u - unit_base[t]);
+        const float cy = cell_centre(g.org[1], g.vs, w.y), cz = cell_centre(g.org[2], g.vs, w.z);
+        const SatRow row = sat_row_setup<EPS>(r.v, cy, cz, g.half);
+        uint32_t mask = 0;
+        if (row.alive) {
+            for (uint32_t x = w.x0; x < w.x1; ++x) {
+                const float cx = cell_centre(g.org[0], g.vs, x);
+                if (sat_row_test<EPS>(row, r.v, cx, g.half)) mask |= 1u << (x & 31u);
+            }
+        }
+        if (STORE_MASK) unit_mask[u] = mask;
+        if (mask) {
+            const uint64_t i0 = (uint64_t)g.dim[0] * ((uint64_t)w.y + (uint64_t)g.dim[1] * w.z) + w.xseg;  // map3dto1d, voxelgrid.hpp:37-40
+            const uint32_t sh = (uint32_t)i0 & 31u;
+            const uint64_t wi = i0 >> 5;
+            const uint32_t lo = mask << sh;
+            const uint32_t hi = sh ? (mask >> (32u - sh)) : 0u;
+            if (lo && wi >= wb && wi < we) { atomicOr(&words[wi], lo); hits += __popc(lo); }        // voxelgridBool.cpp:66
+            if (hi && wi + 1 >= wb && wi + 1 < we) { atomicOr(&words[wi + 1], hi); hits += __popc(hi); }
+        }
+    }
+    hits = wave_sum_u32(hits);
+    if ((threadIdx.x & 63) == 0 && hits) atomicAdd(set_calls, (unsigned long long)hits);
+}
+
+void launch_voxelize(const TriRec* recs, const uint32_t* unit_base, uint32_t ntri, const GridParams& g, int sat_variant, uint32_t /*zlo*/,
+                     uint32_t* words, uint64_t wb, uint64_t we, uint32_t* unit_mask, unsigned long long* set_calls, hipStream_t s)
+{
+    if (!ntri) return;
+    const dim3 grid(kMaxBlocks), block(256);
+    if (sat_variant == 0) {
+        if (unit_mask) hipLaunchKernelGGL((k_voxelize<true, true>), grid, block, 0, s, recs, unit_base, ntri, g, words, wb, we, unit_mask, set_calls);
+        else hipLaunchKernelGGL((k_voxelize<true, false>), grid, block, 0, s, recs, unit_base, ntri, g, words, wb, we, unit_mask, set_calls);
+    } else {
+        if (unit_mask) hipLaunchKernelGGL((k_voxelize<false, true>), grid, block, 0, s, recs, unit_base, ntri, g, words, wb, we, unit_mask, set_calls);
+        else hipLaunchKernelGGL((k_voxelize<false, false>), grid, block, 0, s, recs, unit_base, ntri, g, words, wb, we, unit_mask, set_calls);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K3  ordered emission with duplicates.  Work units are laid out triangle-major, then z, y, x: exactly the order
+// of the reference's loop nest (VoxelBuilder.hpp:186-195), so hit_base (exclusive scan of popc(unit_mask)) is the
+// position of a unit's first hit in VoxelGridVec::m_voxel / in the octree's pre-sort item list.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_emit_units(const TriRec* __restrict__ recs, const uint32_t* __restrict__ unit_base, uint32_t ntri,
+                                                    GridParams g, const uint32_t* __restrict__ unit_mask,
+                                                    const uint32_t* __restrict__ hit_base, vx_aabb* __restrict__ aabbs,
+                                                    uint64_t* __restrict__ morton)
+{
+    const uint32_t U = unit_base[ntri];
+    for (uint64_t u64 = (uint64_t)blockIdx.x * 256u + threadIdx.x; u64 < U; u64 += (uint64_t)gridDim.x * 256u) {
+        const uint32_t u = (uint32_t)u64;
+        uint32_t mask = unit_mask[u];
+        if (!mask) continue;
+        const uint32_t t = find_tri(unit_base, ntri, u);
+        const TriRec r = load_rec(recs, t);
+        const Unit w = decode_unit(r, t, u - unit_base[t]);
+        uint64_t off = hit_base[u];
+        while (mask) {
+            const uint32_t b = __ffs(mask) - 1;
+            mask &= mask - 1;
+            const uint32_t x = w.xseg + b;
+            if (aabbs) {
+                float bb[6];
+                cell_aabb(g, x, w.y, w.z, bb);
+                float2* o = reinterpret_cast<float2*>(aabbs + off);
+                o[0] = make_float2(bb[0], bb[1]);
+                o[1] = make_float2(bb[2], bb[3]);
+                o[2] = make_float2(bb[4], bb[5]);
+            }
+            if (morton) morton[off] = morton3d(x, w.y, w.z);  // octTree.hpp:765
+            ++off;
+        }
+    }
+}
+
+void launch_emit_units(const TriRec* recs, const uint32_t* unit_base, uint32_t ntri, const GridParams& g, uint32_t /*zlo*/,
+                       const uint32_t* unit_mask, const uint32_t* hit_base, vx_aabb* aabbs, uint64_t* morton, hipStream_t s)
+{
+    if (!ntri) return;
+    hipLaunchKernelGGL(k_emit_units, dim3(kMaxBlocks), dim3(256), 0, s, recs, unit_base, ntri, g, unit_mask, hit_base, aabbs, morton);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K4  VoxelGridBool::getAabbs: ascending word, ascending bit.  word_prefix[w] = number of set bits before word w.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_emit_bool(const uint32_t* __restrict__ words, const uint32_t* __restrict__ word_prefix, GridParams g,
+                                                   vx_aabb* __restrict__ out, uint64_t capacity)
+{
+    const uint64_t XY = (uint64_t)g.dim[0] * g.dim[1];
+    for (uint64_t w = (uint64_t)blockIdx.x * 256u + threadIdx.x; w < g.nwords; w += (uint64_t)gridDim.x * 256u) {
+        uint32_t v = words[w];
+        if (!v) continue;
+        uint64_t off = word_prefix[w];
+        const uint64_t i0 = w * 32ull;
+        uint32_t z = (uint32_t)(i0 / XY);
+        const uint32_t rem = (uint32_t)(i0 - (uint64_t)z * XY);
+        uint32_t y = rem / g.dim[0];
+        const uint32_t xb = rem - y * g.dim[0];
+        uint32_t adv = 0;  // x offset already folded into (y,z)
+        while (v) {
+            const uint32_t b = __ffs(v) - 1;
+            v &= v - 1;
+            if (i0 + b >= g.nvox) break;                                   // voxelgridBool.cpp:35
+            uint32_t x = xb + b - adv;
+            while (x >= g.dim[0]) { x -= g.dim[0]; adv += g.dim[0]; if (++y == g.dim[1]) { y = 0; ++z; } }
+            if (off < capacity) {
+                float bb[6];
+                cell_aabb(g, x, y, z, bb);
+                float2* o = reinterpret_cast<float2*>(out + off);
+                o[0] = make_float2(bb[0], bb[1]);
+                o[1] = make_float2(bb[2], bb[3]);
+                o[2] = make_float2(bb[4], bb[5]);
+            }
+            ++off;
+        }
+    }
+}
+
+void launch_emit_bool_aabbs(const uint32_t* words, const uint32_t* word_prefix, const GridParams& g, vx_aabb* out, uint64_t capacity,
+                            hipStream_t s)
+{
+    if (!g.nwords) return;
+    hipLaunchKernelGGL(k_emit_bool, dim3(grid_for(g.nwords, 256, kMaxBlocks)), dim3(256), 0, s, words, word_prefix, g, out, capacity);
+}
+
+// Octree::getAabbs: DFS over the node array visits items in sorted order (octTree.hpp:374-392); decode + AABB per item.
+__global__ __launch_bounds__(256) void k_emit_morton_aabbs(const uint64_t* __restrict__ items, uint64_t n, float ox, float oy, float oz,
+                                                           float vs, vx_aabb* __restrict__ out)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u) {
+        const uint64_t m = items[i];
+        GridParams g;
+        g.org[0] = ox; g.org[1] = oy; g.org[2] = oz; g.vs = vs; g.half = vs * 0.5f;
+        float bb[6];
+        cell_aabb(g, compact_bits(m), compact_bits(m >> 1), compact_bits(m >> 2), bb);
+        float2* o = reinterpret_cast<float2*>(out + i);
+        o[0] = make_float2(bb[0], bb[1]);
+        o[1] = make_float2(bb[2], bb[3]);
+        o[2] = make_float2(bb[4], bb[5]);
+    }
+}
+void launch_emit_morton_aabbs(const uint64_t* items, uint64_t n, const float root_min[3], float vs, vx_aabb* out, hipStream_t s)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(k_emit_morton_aabbs, dim3(grid_for(n, 256, kMaxBlocks)), dim3(256), 0, s, items, n, root_min[0], root_min[1],
+                       root_min[2], vs, out);
+}
+
+__global__ void k_set_bit(uint32_t* words, uint64_t idx) { atomicOr(&words[idx >> 5], 1u << (idx & 31)); }
+void launch_set_bit(uint32_t* words, uint64_t idx, hipStream_t s) { hipLaunchKernelGGL(k_set_bit, dim3(1), dim3(1), 0, s, words, idx); }
+
+// ------------------------------------------------------------------------------------------------------------
+// Coarse occupancy mip (8^3 fine cells per coarse cell) for empty-space skipping in K6.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_build_coarse(const uint32_t* __restrict__ words, GridParams g, uint32_t cx, uint32_t cy, uint32_t cz,
+                                                      uint32_t* __restrict__ cwords)
+{
+    const uint64_t ncoarse = (uint64_t)cx * cy * cz;
+    for (uint64_t c = (uint64_t)blockIdx.x * 256u + threadIdx.x; c < ncoarse; c += (uint64_t)gridDim.x * 256u) {
+        const uint32_t kz = (uint32_t)(c / ((uint64_t)cx * cy));
+        const uint32_t rem = (uint32_t)(c - (uint64_t)kz * cx * cy);
+        const uint32_t ky = rem / cx, kx = rem - ky * cx;
+        const uint32_t x0 = kx * kCoarse;
+        const uint32_t nb = (g.dim[0] - x0) < kCoarse ? (g.dim[0] - x0) : kCoarse;
+        uint32_t any = 0;
+        for (uint32_t fz = 0; fz < kCoarse; ++fz) {
+            const uint32_t z = kz * kCoarse + fz;
+            if (z >= g.dim[2]) break;
+            for (uint32_t fy = 0; fy < kCoarse; ++fy) {
+                const uint32_t y = ky * kCoarse + fy;
+                if (y >= g.dim[1]) break;
+                const uint64_t i0 = (uint64_t)g.dim[0] * ((uint64_t)y + (uint64_t)g.dim[1] * z) + x0;
+                const uint32_t sh = (uint32_t)i0 & 31u;
+                const uint64_t wi = i0 >> 5;
+                uint32_t val = words[wi] >> sh;
+                if (sh + nb > 32u) val |= words[wi + 1] << (32u - sh);
+                any |= val & ((1u << nb) - 1u);
+            }
+        }
+        if (any) atomicOr(&cwords[c >> 5], 1u << (c & 31));
+    }
+}
+
+void launch_build_coarse(const uint32_t* words, const GridParams& g, const uint32_t cdim[3], uint32_t* cwords, hipStream_t s)
+{
+    const uint64_t nc = (uint64_t)cdim[0] * cdim[1] * cdim[2];
+    if (!nc) return;
+    hipMemsetAsync(cwords, 0, (size_t)((nc + 31) / 32) * 4, s);
+    hipLaunchKernelGGL(k_build_coarse, dim3(grid_for(nc, 256, kMaxBlocks)), dim3(256), 0, s, words, g, cdim[0], cdim[1], cdim[2], cwords);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K6  first hit per ray.
+//
+// The reference hands the occupied voxels' AABBs to the driver's BVH and runs raytrace.rint on every candidate; the
+// result per ray is min over ALL boxes of t0 = hitAabb(box) subject to t0 > 0 (rint:69) and tmin <= t0 <= tmax.
+// Here the occupancy bitmask itself is the acceleration structure: a two-level 3D-DDA (8^3-cell bricks over a coarse
+// mip, then cells) enumerates a SUPERSET of the cells the ray can touch, and every occupied visited cell is put
+// through the exact rint formula on the exact float box the reference would have built for it, so the reported t is
+// the same float the brute-force minimum yields.
+//
+// Conservative enumeration: a cell's float box differs from the nominal lattice planes by a few ulps of the largest
+// coordinate, so whenever two plane crossings are closer in t than that tolerance (per axis: tau = tol_pos*|1/d|)
+// the cells on the other side of the near-tie are probed as well, both forward (next planes) and backward (planes
+// just crossed).  Traversal stops once the entry time of the current cell exceeds the best hit by more than tau.
+// ------------------------------------------------------------------------------------------------------------
+struct RayCtx {
+    float ox, oy, oz, dx, dy, dz, ix, iy, iz;  // origin, direction, 1/direction
+    float taux, tauy, tauz;                    // crossing-time tolerance per axis
+    int sx, sy, sz;                            // step direction (+1/-1)
+};
+
+struct TraceState {
+    float best;
+    uint64_t best_idx;
+};
+
+__device__ __forceinline__ float plane_t(float org, float vs, float o, float inv, int fine_index) { return ((org + (float)fine_index * vs) - o) * inv; }
+
+// Generic DDA over cells of edge (1<<S) fine cells, cell indices restricted to [lo, hi).  VISIT(cx,cy,cz,t_in,t_out).
+template <int S, class Visit>
+__device__ __forceinline__ void dda_walk(const RayCtx& R, const GridParams& g, int lox, int loy, int loz, int hix, int hiy, int hiz, float t_lo,
+                                         float t_hi, const TraceState& st, int max_iter, Visit&& visit)
+{
+    const float tauS = R.taux + R.tauy + R.tauz;
+    int cx, cy, cz;
+    float tMx, tMy, tMz, tPx, tPy, tPz;
+#define VX_INIT_AXIS(c, tM, tP, o, d, inv, stp, org, lo, hi)                                  \
+    {                                                                                          \
+        const float p = (o) + t_lo * (d);                                                      \
+        int fi = (int)floorf((p - (org)) / g.vs);                                              \
+        int ci = fi >> S;                                                                      \
+        ci = ci < (lo) ? (lo) : ci;                                                            \
+        ci = ci > (hi)-1 ? (hi)-1 : ci;                                                        \
+        c = ci;                                                                                \
+        if ((d) == 0.0f) { tM = INFINITY; tP = -INFINITY; }                                    \
+        else {                                                                                 \
+            tM = plane_t(org, g.vs, o, inv, (ci + ((stp) > 0 ? 1 : 0)) << S);                  \
+            tP = plane_t(org, g.vs, o, inv, (ci + ((stp) > 0 ? 0 : 1)) << S);                  \
+        }                                                                                      \
+    }
+    VX_INIT_AXIS(cx, tMx, tPx, R.ox, R.dx, R.ix, R.sx, g.org[0], lox, hix)
+    VX_INIT_AXIS(cy, tMy, tPy, R.oy, R.dy, R.iy, R.sy, g.org[1], loy, hiy)
+    VX_INIT_AXIS(cz, tMz, tPz, R.oz, R.dz, R.iz, R.sz, g.org[2], loz, hiz)
+#undef VX_INIT_AXIS
+    float t_in = t_lo;
+    int entry = -1;  // axis through which the current cell was entered
+    for (int it = 0; it < max_iter; ++it) {
+        const bool ex = (tMx <= tMy) && (tMx <= tMz);
+        const bool ey = !ex && (tMy <= tMz);
+        const bool ez = !ex && !ey;
+        const float t_out = ex ? tMx : (ey ? tMy : tMz);
+        const float tau_exit = ex ? R.taux : (ey ? R.tauy : R.tauz);
+        const float tau_entry = entry == 0 ? R.taux : (entry == 1 ? R.tauy : (entry == 2 ? R.tauz : 0.0f));
+        // forward near-ties (other axes' next planes), backward near-ties (planes just behind)
+        const bool fx = !ex && (tMx - t_out <= tau_exit + R.taux);
+        const bool fy = !ey && (tMy - t_out <= tau_exit + R.tauy);
+        const bool fz = !ez && (tMz - t_out <= tau_exit + R.tauz);
+        const bool bx = entry != 0 && (t_in - tPx <= R.taux + (entry < 0 ? R.taux : tau_entry));
+        const bool by = entry != 1 && (t_in - tPy <= R.tauy + (entry < 0 ? R.tauy : tau_entry));
+        const bool bz = entry != 2 && (t_in - tPz <= R.tauz + (entry < 0 ? R.tauz : tau_entry));
+        const bool any = fx | fy | fz | bx | by | bz;
+        const int ncomb = any ? 27 : 1;
+        for (int j = 0; j < ncomb; ++j) {
+            const int jx = j % 3, jy = (j / 3) % 3, jz = j / 9;  // 0: stay, 1: forward, 2: backward
+            const bool okx = jx == 0 || (jx == 1 ? fx : bx);
+            const bool oky = jy == 0 || (jy == 1 ? fy : by);
+            const bool okz = jz == 0 || (jz == 1 ? fz : bz);
+            if (!(okx && oky && okz)) continue;
+            const int nx = cx + (jx == 0 ? 0 : (jx == 1 ? R.sx : -R.sx));
+            const int ny = cy + (jy == 0 ? 0 : (jy == 1 ? R.sy : -R.sy));
+            const int nz = cz + (jz == 0 ? 0 : (jz == 1 ? R.sz : -R.sz));
+            if (nx < lox || nx >= hix || ny < loy || ny >= hiy || nz < loz || nz >= hiz) continue;
+            visit(nx, ny, nz, t_in, t_out);
+        }
+        const float lim = fminf(t_hi, st.best + tauS);
+        if (!(t_out <= lim)) break;
+        if (ex) {
+            cx += R.sx;
+            if (cx < lox || cx >= hix) break;
+            tPx = tMx;
+            tMx = plane_t(g.org[0], g.vs, R.ox, R.ix, (cx + (R.sx > 0 ? 1 : 0)) << S);
+            entry = 0;
+        } else if (ey) {
+            cy += R.sy;
+            if (cy < loy || cy >= hiy) break;
+            tPy = tMy;
+            tMy = plane_t(g.org[1], g.vs, R.oy, R.iy, (cy + (R.sy > 0 ? 1 : 0)) << S);
+            entry = 1;
+        } else {
+            cz += R.sz;
+            if (cz < loz || cz >= hiz) break;
+            tPz = tMz;
+            tMz = plane_t(g.org[2], g.vs, R.oz, R.iz, (cz + (R.sz > 0 ? 1 : 0)) << S);
+            entry = 2;
+        }
+        t_in = t_out;
+    }
+}
+
+template <bool PRIMARY, bool WANT_PRIM>
+__global__ __launch_bounds__(256) void k_trace(GridParams g, uint32_t cdx, uint32_t cdy, uint32_t cdz, const uint32_t* __restrict__ words,
+                                               const uint32_t* __restrict__ cwords, const uint32_t* __restrict__ word_prefix,
+                                               const float* __restrict__ rays, Camera cam, uint64_t nrays, float tmin, float tmax,
+                                               float* __restrict__ t_out, uint32_t* __restrict__ prim_out, vx_hit* __restrict__ hits,
+                                               unsigned long long* nhits)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const bool active = r < nrays;
+    float best_t = -1.0f;
+    uint32_t best_prim = 0xFFFFFFFFu;
+    if (active) {
+        RayCtx R;
+        if (PRIMARY) {
+            // raytrace.rgen:41-47; mat*vec in glm's association (m0*v0 + m1*v1) + (m2*v2 + m3*v3)
+            const uint32_t px = (uint32_t)(r % cam.width), py = (uint32_t)(r / cam.width);
+            const float u = ((float)px + 0.5f) / (float)cam.width, v = ((float)py + 0.5f) / (float)cam.height;
+            const float ndx = u * 2.0f - 1.0f, ndy = v * 2.0f - 1.0f;
+            float tg[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                tg[k] = (cam.projInv[0 + k] * ndx + cam.projInv[4 + k] * ndy) + (cam.projInv[8 + k] * 1.0f + cam.projInv[12 + k] * 1.0f);
+            const float il = 1.0f / sqrtf((tg[0] * tg[0] + tg[1] * tg[1]) + tg[2] * tg[2]);
+            const float n0 = tg[0] * il, n1 = tg[1] * il, n2 = tg[2] * il;
+            R.ox = cam.viewInv[12]; R.oy = cam.viewInv[13]; R.oz = cam.viewInv[14];
+            R.dx = (cam.viewInv[0] * n0 + cam.viewInv[4] * n1) + cam.viewInv[8] * n2;
+            R.dy = (cam.viewInv[1] * n0 + cam.viewInv[5] * n1) + cam.viewInv[9] * n2;
+            R.dz = (cam.viewInv[2] * n0 + cam.viewInv[6] * n1) + cam.viewInv[10] * n2;
+        } else {
+            const float2* rp = reinterpret_cast<const float2*>(rays + 6 * r);
+            const float2 a = rp[0], b = rp[1], c = rp[2];
+            R.ox = a.x; R.oy = a.y; R.oz = b.x; R.dx = b.y; R.dy = c.x; R.dz = c.y;
+        }
+        R.ix = 1.0f / R.dx; R.iy = 1.0f / R.dy; R.iz = 1.0f / R.dz;  // rint:48
+        R.sx = R.dx < 0.0f ? -1 : 1; R.sy = R.dy < 0.0f ? -1 : 1; R.sz = R.dz < 0.0f ? -1 : 1;
+        const float hx = g.org[0] + (float)g.dim[0] * g.vs, hy = g.org[1] + (float)g.dim[1] * g.vs, hz = g.org[2] + (float)g.dim[2] * g.vs;
+        float M = fmaxf(fmaxf(fabsf(R.ox), fabsf(R.oy)), fabsf(R.oz));
+        M = fmaxf(M, fmaxf(fmaxf(fabsf(g.org[0]), fabsf(g.org[1])), fabsf(g.org[2])));
+        M = fmaxf(M, fmaxf(fmaxf(fabsf(hx), fabsf(hy)), fabsf(hz)));
+        const float tolp = M * 9.5367431640625e-07f;  // 16 * 2^-24 * M: covers the <=3-ulp box-plane rounding plus our own
+        R.taux = R.dx == 0.0f ? 0.0f : tolp * fabsf(R.ix);
+        R.tauy = R.dy == 0.0f ? 0.0f : tolp * fabsf(R.iy);
+        R.tauz = R.dz == 0.0f ? 0.0f : tolp * fabsf(R.iz);
+        // entry/exit of the (slightly dilated) grid box
+        float tn = 0.0f, tf = tmax;
+        bool miss = false;
+#define VX_CLIP(o, d, inv, lo, hi)                                                        \
+    if ((d) == 0.0f) { miss |= ((o) < (lo)-tolp) || ((o) > (hi) + tolp); }                 \
+    else {                                                                                 \
+        const float t1 = (((lo)-tolp) - (o)) * (inv), t2 = (((hi) + tolp) - (o)) * (inv);  \
+        tn = fmaxf(tn, fminf(t1, t2));                                                     \
+        tf = fminf(tf, fmaxf(t1, t2));                                                     \
+    }
+        VX_CLIP(R.ox, R.dx, R.ix, g.org[0], hx)
+        VX_CLIP(R.oy, R.dy, R.iy, g.org[1], hy)
+        VX_CLIP(R.oz, R.dz, R.iz, g.org[2], hz)
+#undef VX_CLIP
+        const float tauS = R.taux + R.tauy + R.tauz;
+        tf += tauS;
+        if (!miss && tn <= tf && g.nvox) {
+            TraceState st;
+            st.best = INFINITY;
+            st.best_idx = ~0ull;
+            const float o3[3] = {R.ox, R.oy, R.oz}, inv3[3] = {R.ix, R.iy, R.iz};
+            const uint64_t X = g.dim[0], XY = (uint64_t)g.dim[0] * g.dim[1];
+            auto test_cell = [&](int x, int y, int z, float, float) {
+                const uint64_t i = (uint64_t)x + X * (uint64_t)y + XY * (uint64_t)z;
+                const uint32_t wv = words[i >> 5];
+                if (!((wv >> (i & 31)) & 1u)) return;
+                float bb[6];
+                cell_aabb(g, (uint32_t)x, (uint32_t)y, (uint32_t)z, bb);
+                const float t = hit_aabb(bb, o3, inv3);                       // rint:46-56
+                if (t > 0.0f && t >= tmin && t <= tmax &&                     // rint:69, rgen:50-51
+                    (t < st.best || (t == st.best && i < st.best_idx))) {
+                    st.best = t;
+                    st.best_idx = i;
+                }
+            };
+            auto visit_brick = [&](int kx, int ky, int kz, float t_in, float t_o) {
+                const uint64_t c = (uint64_t)kx + (uint64_t)cdx * ((uint64_t)ky + (uint64_t)cdy * kz);
+                if (!((cwords[c >> 5] >> (c & 31)) & 1u)) return;
+                const int lx = kx << kCoarseShift, ly = ky << kCoarseShift, lz = kz << kCoarseShift;
+                const int ux = min(lx + (int)kCoarse, (int)g.dim[0]), uy = min(ly + (int)kCoarse, (int)g.dim[1]),
+                          uz = min(lz + (int)kCoarse, (int)g.dim[2]);
+                dda_walk<0>(R, g, lx, ly, lz, ux, uy, uz, fmaxf(t_in - tauS, tn), t_o + tauS, st, 3 * (int)kCoarse + 4, test_cell);
+            };
+            dda_walk<kCoarseShift>(R, g, 0, 0, 0, (int)cdx, (int)cdy, (int)cdz, tn, tf, st, (int)(cdx + cdy + cdz) + 4, visit_brick);
+            if (st.best_idx != ~0ull) {
+                best_t = st.best;
+                if (WANT_PRIM) {
+                    const uint64_t wi = st.best_idx >> 5;
+                    const uint32_t bit = (uint32_t)st.best_idx & 31u;
+                    best_prim = word_prefix[wi] + __popc(words[wi] & ((1u << bit) - 1u));  // rank == gl_PrimitiveID
+                } else
+                    best_prim = 0;
+            }
+        }
+        if (t_out) t_out[r] = best_t;
+        if (WANT_PRIM && prim_out) prim_out[r] = best_prim;
+    }
+    if (hits) {
+        // wavefront hit compaction: ballot + prefix popcount, one atomic per wave
+        const bool hit = active && best_t > 0.0f;
+        const unsigned long long bal = __ballot(hit);
+        if (bal) {
+            const int lane = threadIdx.x & 63;
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(nhits, (unsigned long long)__popcll(bal));
+            base = ((unsigned long long)__shfl((unsigned)(base >> 32), 0, 64) << 32) | __shfl((unsigned)base, 0, 64);
+            if (hit) {
+                const unsigned pre = __popcll(bal & ((1ull << lane) - 1ull));
+                vx_hit h;
+                h.ray = (uint32_t)r; h.prim = best_prim; h.t = best_t;
+                hits[base + pre] = h;
+            }
+        }
+    }
+}
+
+void launch_trace(const GridParams& g, const uint32_t cdim[3], const uint32_t* words, const uint32_t* cwords, const uint32_t* word_prefix,
+                  const float* rays, const Camera* cam, uint64_t nrays, float tmin, float tmax, float* t_out, uint32_t* prim_out,
+                  vx_hit* hits, unsigned long long* nhits, hipStream_t s)
+{
+    if (!nrays) return;
+    if (hits && nhits) hipMemsetAsync(nhits, 0, sizeof(unsigned long long), s);
+    Camera c{};
+    if (cam) c = *cam;
+    const dim3 grid((unsigned)((nrays + 255) / 256)), block(256);
+    const bool want_prim = word_prefix != nullptr;
+#define VX_LAUNCH(P, W) \
+    hipLaunchKernelGGL((k_trace<P, W>), grid, block, 0, s, g, cdim[0], cdim[1], cdim[2], words, cwords, word_prefix, rays, c, nrays, tmin, tmax, t_out, prim_out, hits, nhits)
+    if (cam) { if (want_prim) VX_LAUNCH(true, true); else VX_LAUNCH(true, false); }
+    else { if (want_prim) VX_LAUNCH(false, true); else VX_LAUNCH(false, false); }
+#undef VX_LAUNCH
+}
+
+}  // namespace vx

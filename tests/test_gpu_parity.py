@@ -1,0 +1,355 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bar: occupancy bitmask, AABB bytes, Vec / octree order bit-exact; first-hit t within 1e-5 of the brute-force minimum
+(in practice bit-equal: the kernel evaluates the same float formula on the same float box).
+"""
+import numpy as np
+import pytest
+
+import oracle
+import vx_scenes
+
+pytestmark = pytest.mark.gpu
+
+CUBE_SIZES = [0.5, 0.3, 0.25, 0.2, 0.1, 0.0625, 0.05]
+
+
+def check_bool(vx, v, t, vs, sat=0, kind=None):
+    vs = np.float32(vs)
+    kind = vx.GRID_BOOL if kind is None else kind
+    mesh = vx.Mesh.from_arrays(v, t)
+    g = vx.Grid.voxelize(mesh, vs, kind, sat_variant=sat)
+    ow, calls, gi = oracle.build_bool(v, t, vs, threads=0 if sat == 0 else 2)
+    d = g.describe()
+    assert d["dim"] == gi["dim"]
+    assert np.array_equal(d["bbox_min"].view(np.uint32), gi["bmin"].view(np.uint32))   # sign of zero included
+    assert np.array_equal(d["bbox_max"].view(np.uint32), gi["bmax"].view(np.uint32))
+    assert np.array_equal(d["bbox_center"], gi["center"])
+    w = g.bitmask()
+    assert np.array_equal(w, ow), "bitmask mismatch: %d differing words" % int((w != ow).sum())
+    oa = oracle.bool_aabbs(ow, gi, vs)
+    a = g.aabbs()
+    assert a.tobytes() == oa.tobytes()
+    assert d["occupied"] == len(oa) and d["set_calls"] == calls and d["triangles"] == len(t)
+    return g, mesh, gi, oa
+
+
+@pytest.mark.parametrize("vs", CUBE_SIZES)
+@pytest.mark.parametrize("sat", [0, 1])
+def test_cube_all_sizes(gpu, vs, sat):
+    """BASELINE configs[0]: cube.obj at voxelsize 0.1 (and the knife-edge neighbours)."""
+    v, t = vx_scenes.cube()
+    g, _, gi, oa = check_bool(gpu, v, t, vs, sat)
+    assert g.memory_bytes() == 4 * ((gi["dim"][0] * gi["dim"][1] * gi["dim"][2] + 31) // 32)
+
+
+@pytest.mark.parametrize("name,vs", [("rotcube", 0.09), ("rotcube", 0.031), ("adversarial", 0.125), ("adversarial", 0.1),
+                                     ("adversarial", 0.0625), ("adversarial", 0.05), ("adversarial", 0.03125),
+                                     ("soup2000", 0.02), ("soup20000", 1.0 / 256), ("blob70k", 2.0 / 64), ("blob70k", 2.0 / 256)])
+@pytest.mark.parametrize("sat", [0, 1])
+def test_scenes_bool(gpu, name, vs, sat):
+    v, t = vx_scenes.scene(name)
+    check_bool(gpu, v, t, vs, sat)
+
+
+def test_atrium_512_bool_and_vec(gpu):
+    """BASELINE configs[2]: ~262k-triangle architectural scene at 512^3, Bool occupancy and the VecEncoding list."""
+    v, t = vx_scenes.scene("atrium262k")
+    vs = np.float32(32.0 / 512)
+    g, mesh, gi, oa = check_bool(gpu, v, t, vs)
+    assert gi["dim"] == (512, 512, 512)
+    gv = gpu.Grid.voxelize(mesh, vs, gpu.GRID_VEC)
+    ov = oracle.build_vec(v, t, vs)
+    av = gv.aabbs()
+    assert len(av) == len(ov) and av.tobytes() == ov.tobytes()
+    assert gv.memory_bytes() == 24 * len(ov)
+    assert np.array_equal(gv.bitmask(), g.bitmask())
+
+
+@pytest.mark.parametrize("name,vs", [("cube", 0.25), ("cube", 0.0625), ("rotcube", 0.09), ("adversarial", 0.1), ("soup2000", 0.02),
+                                     ("blob70k", 2.0 / 64)])
+def test_vec_and_aabbstruct(gpu, name, vs):
+    v, t = vx_scenes.scene(name)
+    vs = np.float32(vs)
+    mesh = gpu.Mesh.from_arrays(v, t)
+    gv = gpu.Grid.voxelize(mesh, vs, gpu.GRID_VEC)
+    ov = oracle.build_vec(v, t, vs)
+    assert gv.aabbs().tobytes() == ov.tobytes()                     # order and duplicates
+    assert gv.describe()["set_calls"] == len(ov)
+    ga = gpu.Grid.voxelize(mesh, vs, gpu.GRID_AABBSTRUCT)
+    oa, by = oracle.build_aabbstruct(v, t, vs)
+    assert ga.aabbs().tobytes() == oa.tobytes()
+    assert ga.memory_bytes() == by
+
+
+@pytest.mark.parametrize("name,vs,max_items", [("cube", 0.25, 16), ("cube", 0.0625, 16), ("rotcube", 0.05, 16), ("rotcube", 0.05, 4),
+                                               ("adversarial", 0.0625, 16), ("soup2000", 0.02, 16), ("blob70k", 2.0 / 64, 16),
+                                               ("blob70k", 2.0 / 64, 1)])
+def test_octree(gpu, name, vs, max_items):
+    v, t = vx_scenes.scene(name)
+    vs = np.float32(vs)
+    mesh = gpu.Mesh.from_arrays(v, t)
+    o = gpu.Octree(mesh, vs, max_items)
+    r = oracle.octree(v, t, vs, max_items=max_items, threads=2)
+    assert o.num_items == len(r["items"]) and o.num_nodes == len(r["nodes"])
+    assert np.array_equal(o.items(), r["items"])
+    assert o.nodes().tobytes() == r["nodes"].tobytes()
+    assert o.aabbs().tobytes() == r["aabbs"].tobytes()
+    assert o.memory_bytes() == r["bytes"]
+    mn, mx = o.root_bounds()
+    assert np.array_equal(mn, r["root_min"]) and np.array_equal(mx, r["root_max"])
+
+
+def test_empty_inputs(gpu):
+    flat_v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    tri = np.array([[0, 1, 2]], np.int32)
+    g = gpu.Grid.voxelize(gpu.Mesh.from_arrays(flat_v, tri), 0.1)
+    d = g.describe()
+    assert d["dim"][2] == 0 and d["occupied"] == 0 and len(g.aabbs()) == 0 and g.bitmask().size == 0
+    v, _ = vx_scenes.cube()
+    g = gpu.Grid.voxelize(gpu.Mesh.from_arrays(v, np.zeros((0, 3), np.int32)), 0.25)
+    assert g.describe()["dim"] == (8, 8, 8) and g.describe()["occupied"] == 0
+    o = gpu.Octree(gpu.Mesh.from_arrays(v, np.zeros((0, 3), np.int32)), 0.25)
+    assert o.num_nodes == 0 and len(o.aabbs()) == 0
+    o = gpu.Octree(gpu.Mesh.from_arrays(flat_v, tri), 0.1)
+    assert o.num_items == 0 and len(o.aabbs()) == 0
+
+
+def test_obj_file_path(gpu, tmp_path):
+    """The `<obj_path> <voxelsize>` entry: parse + voxelize == arrays + voxelize."""
+    v, t = vx_scenes.rotated_cube()
+    p = tmp_path / "rot.obj"
+    vx_scenes.write_obj(str(p), v, t)
+    g = gpu.Grid.voxelize(gpu.Mesh.load_obj(str(p)), 0.07)
+    ow, _, gi = oracle.build_bool(v, t, 0.07)
+    assert np.array_equal(g.bitmask(), ow)
+
+
+def test_grid_setvoxel_api(gpu):
+    """VoxelGrid ctor / setVoxel / getCorrds / bounds errors (voxelgrid.hpp:52-100, voxelgridBool.cpp:54-68)."""
+    org = (0.5, -1.25, 3.0)
+    for kind in (gpu.GRID_BOOL, gpu.GRID_AABBSTRUCT, gpu.GRID_VEC):
+        g = gpu.Grid.create(kind, 5, 7, 3, 0.3, org)
+        pts = [(0, 0, 0), (4, 6, 2), (2, 3, 1), (2, 3, 1)]
+        for p in pts:
+            g.set_voxel(*p)
+        assert g.test_voxel(2, 3, 1) and not g.test_voxel(1, 1, 1)
+        gi = dict(dim=(5, 7, 3), bmin=np.array(org, np.float32))
+        words = np.zeros(4, np.uint32)
+        for x, y, z in pts:
+            i = x + 5 * (y + 7 * z)
+            words[i // 32] |= np.uint32(1 << (i % 32))
+        exp = oracle.bool_aabbs(words, gi, np.float32(0.3))
+        a = g.aabbs()
+        if kind == gpu.GRID_VEC:
+            assert len(a) == 4 and a[2].tobytes() == a[3].tobytes()     # duplicates kept, insertion order
+            assert set(map(bytes, a.view(np.uint8).reshape(-1, 24))) == set(map(bytes, exp.view(np.uint8).reshape(-1, 24)))
+        else:
+            assert a.tobytes() == exp.tobytes()
+        c = g.coords(2, 3, 1)
+        assert np.array_equal(c, np.array(org, np.float32) + (np.array([2, 3, 1], np.float32) + np.float32(0.5)) * np.float32(0.3))
+        with pytest.raises(gpu.VxError) as e:
+            g.set_voxel(5, 0, 0)
+        assert e.value.status == 4 and e.value.message == "Index out of bounds"
+        with pytest.raises(gpu.VxError):
+            g.coords(0, 7, 0)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_word_shards_or_to_full_mask(gpu, world):
+    """Multi-GPU partition on one device: each logical rank writes only its word range; the shards are word-disjoint
+    and their concatenation equals the single-GPU bitmask."""
+    v, t = vx_scenes.scene("adversarial")
+    vs = np.float32(0.03125)
+    mesh = gpu.Mesh.from_arrays(v, t)
+    full = gpu.Grid.voxelize(mesh, vs).bitmask()
+    acc = np.zeros_like(full)
+    for r in range(world):
+        b, e, _ = gpu.shard_words(full.size, r, world)
+        w = gpu.Grid.voxelize(mesh, vs, words=(b, e)).bitmask()
+        assert not w[:b].any() and not w[e:].any()
+        assert np.array_equal(w[b:e], full[b:e])
+        acc |= w
+    assert np.array_equal(acc, full)
+
+
+def test_triangle_shards_concat_to_vec_list(gpu):
+    v, t = vx_scenes.scene("soup2000")
+    vs = np.float32(0.02)
+    mesh = gpu.Mesh.from_arrays(v, t)
+    full = gpu.Grid.voxelize(mesh, vs, gpu.GRID_VEC).aabbs()
+    parts = []
+    for r in range(3):
+        b, e = gpu.shard_range(len(t), r, 3)
+        parts.append(gpu.Grid.voxelize(mesh, vs, gpu.GRID_VEC, tris=(b, e)).aabbs())
+    assert np.concatenate(parts).tobytes() == full.tobytes()
+
+
+# ---------------------------------------------------------------------------------------------- rays
+def corner_rays(gi, vs, n, seed):
+    """Rays aimed exactly at voxel lattice corners / edge midpoints: the grazing cases of the DDA."""
+    rng = np.random.default_rng(seed)
+    dim = np.array(gi["dim"])
+    bmin = gi["bmin"].astype(np.float64)
+    ctr = bmin + dim * vs / 2
+    R = 2.5 * np.linalg.norm(dim * vs)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    o = (ctr + R * d).astype(np.float32)
+    k = rng.integers(0, dim + 1, size=(n, 3)).astype(np.float64)
+    k[: n // 2] += rng.choice([0.0, 0.5], size=(n // 2, 3))
+    tgt = (bmin + k * vs).astype(np.float32)
+    dr = tgt.astype(np.float64) - o.astype(np.float64)
+    dr = (dr / np.linalg.norm(dr, axis=1, keepdims=True)).astype(np.float32)
+    dr[dr == 0] = np.float32(1e-20)
+    return np.ascontiguousarray(np.concatenate([o, dr], axis=1))
+
+
+def axis_rays(gi, vs, n, seed):
+    """Nearly axis-parallel rays running inside / along lattice planes."""
+    rng = np.random.default_rng(seed)
+    dim = np.array(gi["dim"])
+    bmin = gi["bmin"].astype(np.float64)
+    rays = np.zeros((n, 6), np.float32)
+    for i in range(n):
+        a = i % 3
+        k = rng.integers(0, dim + 1).astype(np.float64)
+        if i % 2:
+            k += 0.5
+        o = bmin + k * vs
+        o[a] = bmin[a] - 3.0 * vs * (1 + rng.uniform())
+        d = rng.uniform(-1, 1, 3) * (1e-7 if i % 4 < 2 else 1e-3)
+        d[a] = 1.0
+        if i % 8 >= 4:
+            o[a] = bmin[a] + (dim[a] + 3.0) * vs
+            d[a] = -1.0
+        rays[i, :3], rays[i, 3:] = o, d
+    rays[:, 3:][rays[:, 3:] == 0] = np.float32(1e-20)
+    return rays
+
+
+def inside_rays(gi, vs, n, seed):
+    rng = np.random.default_rng(seed)
+    dim = np.array(gi["dim"])
+    bmin = gi["bmin"].astype(np.float64)
+    o = bmin + rng.uniform(0, 1, (n, 3)) * dim * vs
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d = d.astype(np.float32)
+    d[d == 0] = np.float32(1e-20)
+    return np.ascontiguousarray(np.concatenate([o.astype(np.float32), d], axis=1))
+
+
+def check_trace(vx, g, oa, rays, tmin=0.001, tmax=10000.0):
+    t, p, nh = g.trace(rays, tmin, tmax)
+    ot, op = oracle.trace_brute(oa, rays, tmin, tmax)
+    bad = np.flatnonzero((t > 0) != (ot > 0))
+    assert bad.size == 0, "hit/miss mismatch on rays %s: gpu %s oracle %s" % (bad[:5], t[bad[:5]], ot[bad[:5]])
+    assert np.allclose(t, ot, rtol=0, atol=1e-5)                    # the north-star tolerance
+    assert np.array_equal(t, ot), "t not bit-equal (max diff %g)" % np.abs(t - ot).max()
+    assert np.array_equal(p, op)
+    assert nh == int((ot > 0).sum())
+    return t
+
+
+@pytest.mark.parametrize("name,vs", [("cube", 0.25), ("cube", 0.0625), ("rotcube", 0.09), ("adversarial", 0.0625), ("adversarial", 0.1),
+                                     ("soup2000", 0.02), ("blob70k", 2.0 / 64)])
+def test_trace_vs_brute_force(gpu, name, vs):
+    v, t = vx_scenes.scene(name)
+    vs = np.float32(vs)
+    mesh = gpu.Mesh.from_arrays(v, t)
+    g = gpu.Grid.voxelize(mesh, vs)
+    ow, _, gi = oracle.build_bool(v, t, vs)
+    oa = oracle.bool_aabbs(ow, gi, vs)
+    n = 20000 if len(oa) < 20000 else 6000
+    hit = check_trace(gpu, g, oa, vx_scenes.random_rays(n, gi["bmin"], gi["bmax"], seed=2))
+    assert (hit > 0).mean() > 0.02
+    check_trace(gpu, g, oa, corner_rays(gi, float(vs), n, 5))
+    check_trace(gpu, g, oa, axis_rays(gi, float(vs), 4000, 6))
+    check_trace(gpu, g, oa, inside_rays(gi, float(vs), n, 7))
+
+
+def test_trace_blob_256(gpu):
+    """BASELINE configs[1]: ~70k-triangle closed mesh, 256^3, random rays vs the CPU first-hit t (sampled: the brute
+    force over 290k boxes is the slow side)."""
+    v, t = vx_scenes.scene("blob70k")
+    vs = np.float32(2.0 / 256)
+    g, mesh, gi, oa = check_bool(gpu, v, t, vs)
+    rays = vx_scenes.random_rays(1_000_000, gi["bmin"], gi["bmax"], seed=2)
+    tt, pp, nh = g.trace(rays)
+    sel = np.random.default_rng(11).choice(len(rays), 3000, replace=False)
+    ot, op = oracle.trace_brute(oa, rays[sel])
+    assert np.array_equal(tt[sel], ot) and np.array_equal(pp[sel], op)
+    # size-independent property on all 1M rays: the reported t is the rint formula of the reported primitive's own box,
+    # and no ray reports a t outside the interval
+    h = np.flatnonzero(tt > 0)
+    assert len(h) == nh and np.all(pp[tt <= 0] == 0xFFFFFFFF)
+    o, d = rays[h, :3], rays[h, 3:]
+    inv = np.float32(1.0) / d
+    b = oa[pp[h]]
+    tb, tp = inv * (b["mn"] - o), inv * (b["mx"] - o)
+    t0 = np.minimum(tb, tp).max(axis=1)
+    assert np.array_equal(t0.astype(np.float32), tt[h])
+    assert np.all(tt[h] >= np.float32(0.001)) and np.all(tt[h] <= np.float32(10000.0))
+
+
+def test_trace_interval_and_compaction(gpu):
+    import torch
+    v, t = vx_scenes.rotated_cube()
+    vs = np.float32(0.09)
+    mesh = gpu.Mesh.from_arrays(v, t)
+    g = gpu.Grid.voxelize(mesh, vs)
+    ow, _, gi = oracle.build_bool(v, t, vs)
+    oa = oracle.bool_aabbs(ow, gi, vs)
+    rays = vx_scenes.random_rays(5000, gi["bmin"], gi["bmax"], seed=3)
+    for tmin, tmax in ((0.001, 10000.0), (9.5, 10000.0), (0.001, 9.3), (9.2, 9.6)):
+        check_trace(gpu, g, oa, rays, tmin, tmax)
+    # device entry point with ballot/prefix hit compaction
+    dr = torch.from_numpy(rays).cuda()
+    dt = torch.empty(len(rays), dtype=torch.float32, device="cuda")
+    dp = torch.empty(len(rays), dtype=torch.int32, device="cuda")
+    dh = torch.zeros(len(rays) * 3, dtype=torch.int32, device="cuda")
+    dn = torch.zeros(1, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    g.trace_device(dr.data_ptr(), len(rays), dt.data_ptr(), dp.data_ptr(), dh.data_ptr(), dn.data_ptr())
+    torch.cuda.synchronize()
+    ot, op = oracle.trace_brute(oa, rays)
+    n = int(dn.item())
+    assert n == int((ot > 0).sum())
+    hits = dh.cpu().numpy().view(np.uint32).reshape(-1, 3)[:n]
+    order = np.argsort(hits[:, 0])
+    hr = hits[order]
+    exp = np.flatnonzero(ot > 0)
+    assert np.array_equal(hr[:, 0], exp) and np.array_equal(hr[:, 1], op[exp]) and np.array_equal(hr[:, 2].view(np.float32), ot[exp])
+
+
+def test_primary_rays_match_generated_rays(gpu):
+    """raytrace.rgen camera model generated in-kernel == explicit rays from the oracle's restatement of it."""
+    import torch
+    v, t = vx_scenes.rotated_cube(half=1.0, offset=(0.0, 1.0, 0.0))
+    vs = np.float32(0.05)
+    g = gpu.Grid.voxelize(gpu.Mesh.from_arrays(v, t), vs)
+    vi, pi = vx_scenes.camera_matrices()
+    W, H = 320, 180
+    rays = oracle.primary_rays(vi, pi, W, H)
+    t_explicit, _, _ = g.trace(rays)
+    dt = torch.empty(W * H, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    g.trace_primary_device(vi, pi, W, H, dt.data_ptr())
+    torch.cuda.synchronize()
+    tp = dt.cpu().numpy()
+    assert (t_explicit > 0).mean() > 0.01
+    assert np.array_equal(tp > 0, t_explicit > 0)
+    assert np.allclose(tp, t_explicit, rtol=0, atol=1e-5)
+
+
+def test_revoxelize_reuses_handle(gpu):
+    v, t = vx_scenes.rotated_cube()
+    mesh = gpu.Mesh.from_arrays(v, t)
+    g = gpu.Grid.voxelize(mesh, 0.09)
+    a = g.bitmask().copy()
+    g.revoxelize(mesh, 0.05)
+    ow, _, gi = oracle.build_bool(v, t, 0.05)
+    assert np.array_equal(g.bitmask(), ow)
+    g.revoxelize(mesh, 0.09)
+    assert np.array_equal(g.bitmask(), a)       # idempotent
