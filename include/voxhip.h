@@ -165,6 +165,12 @@ vx_status vx_trace_primary_device(const vx_grid* g, const float view_inverse[16]
                                   uint32_t width, uint32_t height, float tmin, float tmax, float* dev_t,
                                   uint32_t* dev_prim /*NULL ok*/);
 
+/* ---- measurement aid: per-kernel durations from HIP events recorded on the launch stream (off by default).
+ * slot = 0,1,... until VX_ERR_INVALID_ARG; name is the kernel symbol as launched. */
+vx_status vx_profile_enable(int on);
+vx_status vx_profile_reset(void);
+vx_status vx_profile_read(int slot, char* name, size_t name_capacity, double* total_ms, uint64_t* launches);
+
 /* ---- multi-GPU helpers (host arithmetic only) ----------------------------------------------------------------
  * Word-aligned shard of the bitmask for rank r of n: contributions of different ranks are word-disjoint, so an
  * all-gather of the shards (or a sum/max all-reduce of zero-padded buffers) equals the OR of the full masks. */

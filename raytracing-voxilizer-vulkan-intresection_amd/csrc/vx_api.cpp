@@ -969,6 +969,23 @@ void vx_octree_free(vx_octree* o)
     delete o;
 }
 
+// ---- per-kernel timing (bench / profiling aid) ----------------------------------------------------------------
+vx_status vx_profile_enable(int on)
+{
+    vx::prof_enable(on != 0);
+    return VX_OK;
+}
+vx_status vx_profile_reset(void)
+{
+    vx::prof_reset();
+    return VX_OK;
+}
+vx_status vx_profile_read(int slot, char* name, size_t name_capacity, double* total_ms, uint64_t* launches)
+{
+    if (vx::prof_read(slot, name, name_capacity, total_ms, launches) != 0) return fail(VX_ERR_INVALID_ARG, "no such profile slot");
+    return VX_OK;
+}
+
 // ---- sharding helpers -----------------------------------------------------------------------------------------
 void vx_shard_words(uint64_t num_words, int rank, int world, uint64_t* wb, uint64_t* we, uint64_t* padded)
 {

@@ -25,6 +25,19 @@ constexpr int kScanTile = kScanBlock * kScanItems;
 
 struct Camera { float viewInv[16]; float projInv[16]; uint32_t width, height; };
 
+// ---- optional per-kernel event timing (vx_prof.cpp) ----------------------------------------------------------
+void prof_enable(bool on);
+bool prof_enabled();
+void prof_reset();
+int prof_read(int slot, char* name, size_t cap, double* ms, uint64_t* n);
+struct ProfScope {
+    ProfScope(const char* name, hipStream_t s);
+    ~ProfScope();
+    const char* name_;
+    hipStream_t s_;
+    hipEvent_t a_;
+};
+
 // ---- launchers (all asynchronous on `s`) ------------------------------------------------------------------
 // K1: bbox of all vertices with the reference's first-occurrence tie rule; out6 = min xyz, max xyz (device).
 void launch_bbox(const float* verts, uint64_t nverts, unsigned long long* keys6, float* out6, hipStream_t s);

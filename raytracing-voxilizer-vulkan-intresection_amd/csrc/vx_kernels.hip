@@ -24,6 +24,13 @@ static inline unsigned grid_for(uint64_t n, unsigned block, unsigned cap)
     if (b > cap) b = cap;
     return (unsigned)b;
 }
+// every kernel launch goes through here so that the optional event profiler (vx_prof.cpp) sees it
+#define VX_KL(kern, grid, block, shmem, stream, ...)                         \
+    do {                                                                     \
+        ProfScope ps_(#kern, stream);                                        \
+        hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__);   \
+    } while (0)
+
 constexpr unsigned kMaxBlocks = 256 * 8;  // 256 CUs x 8 resident 256-thread blocks: grid-stride beyond that
 
 // ------------------------------------------------------------------------------------------------------------
@@ -107,8 +114,8 @@ void launch_bbox(const float* verts, uint64_t nverts, unsigned long long* keys6,
 {
     static const unsigned long long init[6] = {~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull};
     hipMemcpyAsync(keys6, init, sizeof(init), hipMemcpyHostToDevice, s);
-    if (nverts) hipLaunchKernelGGL(k_bbox, dim3(grid_for(nverts, 256, kMaxBlocks)), dim3(256), 0, s, verts, nverts, keys6);
-    hipLaunchKernelGGL(k_bbox_finish, dim3(1), dim3(64), 0, s, verts, nverts, keys6, out6);
+    if (nverts) VX_KL(k_bbox, dim3(grid_for(nverts, 256, kMaxBlocks)), dim3(256), 0, s, verts, nverts, keys6);
+    VX_KL(k_bbox_finish, dim3(1), dim3(64), 0, s, verts, nverts, keys6, out6);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -222,13 +229,13 @@ void launch_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, bool popcoun
     const uint32_t nblocks = (uint32_t)(((n + 1) + kScanTile - 1) / kScanTile);
     unsigned long long* sums = (unsigned long long*)tmp;
     if (popcount_input) {
-        hipLaunchKernelGGL(k_scan_sums<true>, dim3(nblocks), dim3(kScanBlock), 0, s, in, n, sums);
-        hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, s, sums, nblocks, total64);
-        hipLaunchKernelGGL(k_scan_apply<true>, dim3(nblocks), dim3(kScanBlock), 0, s, in, out, n, sums);
+        VX_KL(k_scan_sums<true>, dim3(nblocks), dim3(kScanBlock), 0, s, in, n, sums);
+        VX_KL(k_scan_spine, dim3(1), dim3(1024), 0, s, sums, nblocks, total64);
+        VX_KL(k_scan_apply<true>, dim3(nblocks), dim3(kScanBlock), 0, s, in, out, n, sums);
     } else {
-        hipLaunchKernelGGL(k_scan_sums<false>, dim3(nblocks), dim3(kScanBlock), 0, s, in, n, sums);
-        hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, s, sums, nblocks, total64);
-        hipLaunchKernelGGL(k_scan_apply<false>, dim3(nblocks), dim3(kScanBlock), 0, s, in, out, n, sums);
+        VX_KL(k_scan_sums<false>, dim3(nblocks), dim3(kScanBlock), 0, s, in, n, sums);
+        VX_KL(k_scan_spine, dim3(1), dim3(1024), 0, s, sums, nblocks, total64);
+        VX_KL(k_scan_apply<false>, dim3(nblocks), dim3(kScanBlock), 0, s, in, out, n, sums);
     }
 }
 
@@ -280,7 +287,7 @@ void launch_tri_setup(const float* verts, const int32_t* idx, uint64_t tri_begin
     if (!ntri) return;
     // serial driver: voxelSize = halfVoxelSize.x * 2.0f (VoxelBuilder.hpp:173); threaded driver: vSize = voxelSize (:500)
     const float vsize = sat_variant == 0 ? g.half * 2.0f : g.vs;
-    hipLaunchKernelGGL(k_tri_setup, dim3((ntri + 255) / 256), dim3(256), 0, s, verts, idx, tri_begin, ntri, g, vsize, zlo, zhi, recs, units);
+    VX_KL(k_tri_setup, dim3((ntri + 255) / 256), dim3(256), 0, s, verts, idx, tri_begin, ntri, g, vsize, zlo, zhi, recs, units);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -383,11 +390,11 @@ void launch_voxelize(const TriRec* recs, const uint32_t* unit_base, uint32_t ntr
     if (!ntri) return;
     const dim3 grid(kMaxBlocks), block(256);
     if (sat_variant == 0) {
-        if (unit_mask) hipLaunchKernelGGL((k_voxelize<true, true>), grid, block, 0, s, recs, unit_base, ntri, g, words, wb, we, unit_mask, set_calls);
-        else hipLaunchKernelGGL((k_voxelize<true, false>), grid, block, 0, s, recs, unit_base, ntri, g, words, wb, we, unit_mask, set_calls);
+        if (unit_mask) VX_KL((k_voxelize<true, true>), grid, block, 0, s, recs, unit_base, ntri, g, words, wb, we, unit_mask, set_calls);
+        else VX_KL((k_voxelize<true, false>), grid, block, 0, s, recs, unit_base, ntri, g, words, wb, we, unit_mask, set_calls);
     } else {
-        if (unit_mask) hipLaunchKernelGGL((k_voxelize<false, true>), grid, block, 0, s, recs, unit_base, ntri, g, words, wb, we, unit_mask, set_calls);
-        else hipLaunchKernelGGL((k_voxelize<false, false>), grid, block, 0, s, recs, unit_base, ntri, g, words, wb, we, unit_mask, set_calls);
+        if (unit_mask) VX_KL((k_voxelize<false, true>), grid, block, 0, s, recs, unit_base, ntri, g, words, wb, we, unit_mask, set_calls);
+        else VX_KL((k_voxelize<false, false>), grid, block, 0, s, recs, unit_base, ntri, g, words, wb, we, unit_mask, set_calls);
     }
 }
 
@@ -432,7 +439,7 @@ void launch_emit_units(const TriRec* recs, const uint32_t* unit_base, uint32_t n
                        const uint32_t* unit_mask, const uint32_t* hit_base, vx_aabb* aabbs, uint64_t* morton, hipStream_t s)
 {
     if (!ntri) return;
-    hipLaunchKernelGGL(k_emit_units, dim3(kMaxBlocks), dim3(256), 0, s, recs, unit_base, ntri, g, unit_mask, hit_base, aabbs, morton);
+    VX_KL(k_emit_units, dim3(kMaxBlocks), dim3(256), 0, s, recs, unit_base, ntri, g, unit_mask, hit_base, aabbs, morton);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -475,7 +482,7 @@ void launch_emit_bool_aabbs(const uint32_t* words, const uint32_t* word_prefix, 
                             hipStream_t s)
 {
     if (!g.nwords) return;
-    hipLaunchKernelGGL(k_emit_bool, dim3(grid_for(g.nwords, 256, kMaxBlocks)), dim3(256), 0, s, words, word_prefix, g, out, capacity);
+    VX_KL(k_emit_bool, dim3(grid_for(g.nwords, 256, kMaxBlocks)), dim3(256), 0, s, words, word_prefix, g, out, capacity);
 }
 
 // Octree::getAabbs: DFS over the node array visits items in sorted order (octTree.hpp:374-392); decode + AABB per item.
@@ -497,12 +504,12 @@ __global__ __launch_bounds__(256) void k_emit_morton_aabbs(const uint64_t* __res
 void launch_emit_morton_aabbs(const uint64_t* items, uint64_t n, const float root_min[3], float vs, vx_aabb* out, hipStream_t s)
 {
     if (!n) return;
-    hipLaunchKernelGGL(k_emit_morton_aabbs, dim3(grid_for(n, 256, kMaxBlocks)), dim3(256), 0, s, items, n, root_min[0], root_min[1],
+    VX_KL(k_emit_morton_aabbs, dim3(grid_for(n, 256, kMaxBlocks)), dim3(256), 0, s, items, n, root_min[0], root_min[1],
                        root_min[2], vs, out);
 }
 
 __global__ void k_set_bit(uint32_t* words, uint64_t idx) { atomicOr(&words[idx >> 5], 1u << (idx & 31)); }
-void launch_set_bit(uint32_t* words, uint64_t idx, hipStream_t s) { hipLaunchKernelGGL(k_set_bit, dim3(1), dim3(1), 0, s, words, idx); }
+void launch_set_bit(uint32_t* words, uint64_t idx, hipStream_t s) { VX_KL(k_set_bit, dim3(1), dim3(1), 0, s, words, idx); }
 
 // ------------------------------------------------------------------------------------------------------------
 // Coarse occupancy mip (8^3 fine cells per coarse cell) for empty-space skipping in K6.
@@ -541,7 +548,7 @@ void launch_build_coarse(const uint32_t* words, const GridParams& g, const uint3
     const uint64_t nc = (uint64_t)cdim[0] * cdim[1] * cdim[2];
     if (!nc) return;
     hipMemsetAsync(cwords, 0, (size_t)((nc + 31) / 32) * 4, s);
-    hipLaunchKernelGGL(k_build_coarse, dim3(grid_for(nc, 256, kMaxBlocks)), dim3(256), 0, s, words, g, cdim[0], cdim[1], cdim[2], cwords);
+    VX_KL(k_build_coarse, dim3(grid_for(nc, 256, kMaxBlocks)), dim3(256), 0, s, words, g, cdim[0], cdim[1], cdim[2], cwords);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -572,10 +579,14 @@ struct TraceState {
 
 __device__ __forceinline__ float plane_t(float org, float vs, float o, float inv, int fine_index) { return ((org + (float)fine_index * vs) - o) * inv; }
 
-// Generic DDA over cells of edge (1<<S) fine cells, cell indices restricted to [lo, hi).  VISIT(cx,cy,cz,t_in,t_out).
-template <int S, class Visit>
+// Generic DDA over cells of edge (1<<S) fine cells.  The walk itself (the cells the nominal ray passes through) is
+// restricted to cell indices [lo, hi), which may reach outside the grid; VISIT(cx,cy,cz) is called for the walk's
+// current cell and for every near-tie neighbour -- neighbours are NOT restricted to [lo, hi) (a neighbour is a cell the
+// nominal ray does not pass through, so it cannot be walked, only looked at) and the visitor bounds-checks against the
+// grid.  POST(cx,cy,cz,t_in,t_out) runs once per step after the visits.
+template <int S, class Visit, class Post>
 __device__ __forceinline__ void dda_walk(const RayCtx& R, const GridParams& g, int lox, int loy, int loz, int hix, int hiy, int hiz, float t_lo,
-                                         float t_hi, const TraceState& st, int max_iter, Visit&& visit)
+                                         float t_hi, const TraceState& st, int max_iter, Visit&& visit, Post&& post)
 {
     const float tauS = R.taux + R.tauy + R.tauz;
     int cx, cy, cz;
@@ -590,8 +601,8 @@ __device__ __forceinline__ void dda_walk(const RayCtx& R, const GridParams& g, i
         c = ci;                                                                                \
         if ((d) == 0.0f) { tM = INFINITY; tP = -INFINITY; }                                    \
         else {                                                                                 \
-            tM = plane_t(org, g.vs, o, inv, (ci + ((stp) > 0 ? 1 : 0)) << S);                  \
-            tP = plane_t(org, g.vs, o, inv, (ci + ((stp) > 0 ? 0 : 1)) << S);                  \
+            tM = plane_t(org, g.vs, o, inv, (ci + ((stp) > 0 ? 1 : 0)) * (1 << S));                  \
+            tP = plane_t(org, g.vs, o, inv, (ci + ((stp) > 0 ? 0 : 1)) * (1 << S));                  \
         }                                                                                      \
     }
     VX_INIT_AXIS(cx, tMx, tPx, R.ox, R.dx, R.ix, R.sx, g.org[0], lox, hix)
@@ -625,28 +636,28 @@ __device__ __forceinline__ void dda_walk(const RayCtx& R, const GridParams& g, i
             const int nx = cx + (jx == 0 ? 0 : (jx == 1 ? R.sx : -R.sx));
             const int ny = cy + (jy == 0 ? 0 : (jy == 1 ? R.sy : -R.sy));
             const int nz = cz + (jz == 0 ? 0 : (jz == 1 ? R.sz : -R.sz));
-            if (nx < lox || nx >= hix || ny < loy || ny >= hiy || nz < loz || nz >= hiz) continue;
-            visit(nx, ny, nz, t_in, t_out);
+            visit(nx, ny, nz);
         }
+        post(cx, cy, cz, t_in, t_out);
         const float lim = fminf(t_hi, st.best + tauS);
         if (!(t_out <= lim)) break;
         if (ex) {
             cx += R.sx;
             if (cx < lox || cx >= hix) break;
             tPx = tMx;
-            tMx = plane_t(g.org[0], g.vs, R.ox, R.ix, (cx + (R.sx > 0 ? 1 : 0)) << S);
+            tMx = plane_t(g.org[0], g.vs, R.ox, R.ix, (cx + (R.sx > 0 ? 1 : 0)) * (1 << S));
             entry = 0;
         } else if (ey) {
             cy += R.sy;
             if (cy < loy || cy >= hiy) break;
             tPy = tMy;
-            tMy = plane_t(g.org[1], g.vs, R.oy, R.iy, (cy + (R.sy > 0 ? 1 : 0)) << S);
+            tMy = plane_t(g.org[1], g.vs, R.oy, R.iy, (cy + (R.sy > 0 ? 1 : 0)) * (1 << S));
             entry = 1;
         } else {
             cz += R.sz;
             if (cz < loz || cz >= hiz) break;
             tPz = tMz;
-            tMz = plane_t(g.org[2], g.vs, R.oz, R.iz, (cz + (R.sz > 0 ? 1 : 0)) << S);
+            tMz = plane_t(g.org[2], g.vs, R.oz, R.iz, (cz + (R.sz > 0 ? 1 : 0)) * (1 << S));
             entry = 2;
         }
         t_in = t_out;
@@ -718,7 +729,8 @@ __global__ __launch_bounds__(256) void k_trace(GridParams g, uint32_t cdx, uint3
             st.best_idx = ~0ull;
             const float o3[3] = {R.ox, R.oy, R.oz}, inv3[3] = {R.ix, R.iy, R.iz};
             const uint64_t X = g.dim[0], XY = (uint64_t)g.dim[0] * g.dim[1];
-            auto test_cell = [&](int x, int y, int z, float, float) {
+            auto test_cell = [&](int x, int y, int z) {
+                if ((unsigned)x >= g.dim[0] || (unsigned)y >= g.dim[1] || (unsigned)z >= g.dim[2]) return;
                 const uint64_t i = (uint64_t)x + X * (uint64_t)y + XY * (uint64_t)z;
                 const uint32_t wv = words[i >> 5];
                 if (!((wv >> (i & 31)) & 1u)) return;
@@ -731,15 +743,30 @@ __global__ __launch_bounds__(256) void k_trace(GridParams g, uint32_t cdx, uint3
                     st.best_idx = i;
                 }
             };
-            auto visit_brick = [&](int kx, int ky, int kz, float t_in, float t_o) {
+            auto no_post = [](int, int, int, float, float) {};
+            // coarse level: a brick is refined when it or any near-tie neighbour brick holds an occupied cell; the fine
+            // walk always covers the NOMINAL brick (the one the ray passes through) and reaches the neighbours' cells
+            // through its own near-tie probes.
+            bool occ = false;
+            auto coarse_visit = [&](int kx, int ky, int kz) {
+                if ((unsigned)kx >= cdx || (unsigned)ky >= cdy || (unsigned)kz >= cdz) return;
                 const uint64_t c = (uint64_t)kx + (uint64_t)cdx * ((uint64_t)ky + (uint64_t)cdy * kz);
-                if (!((cwords[c >> 5] >> (c & 31)) & 1u)) return;
-                const int lx = kx << kCoarseShift, ly = ky << kCoarseShift, lz = kz << kCoarseShift;
-                const int ux = min(lx + (int)kCoarse, (int)g.dim[0]), uy = min(ly + (int)kCoarse, (int)g.dim[1]),
-                          uz = min(lz + (int)kCoarse, (int)g.dim[2]);
-                dda_walk<0>(R, g, lx, ly, lz, ux, uy, uz, fmaxf(t_in - tauS, tn), t_o + tauS, st, 3 * (int)kCoarse + 4, test_cell);
+                occ |= ((cwords[c >> 5] >> (c & 31)) & 1u) != 0u;
             };
-            dda_walk<kCoarseShift>(R, g, 0, 0, 0, (int)cdx, (int)cdy, (int)cdz, tn, tf, st, (int)(cdx + cdy + cdz) + 4, visit_brick);
+            auto coarse_post = [&](int kx, int ky, int kz, float t_in, float) {
+                if (!occ) return;
+                occ = false;
+                const int lx = kx << kCoarseShift, ly = ky << kCoarseShift, lz = kz << kCoarseShift;
+                // start exactly at the brick's entry time (a time slack would slide the start point along the ray's major
+                // axis); the start cell's own rounding is covered by the walk's backward/forward probes; the walk ends
+                // when it leaves the brick.
+                dda_walk<0>(R, g, lx, ly, lz, lx + (int)kCoarse, ly + (int)kCoarse, lz + (int)kCoarse, fmaxf(t_in, tn), INFINITY, st,
+                            3 * (int)kCoarse + 4, test_cell, no_post);
+            };
+            // one virtual coarse cell of halo around the grid: a ray sliding along the outside of a boundary face within
+            // tolerance still walks next to the boundary bricks and probes into them
+            dda_walk<kCoarseShift>(R, g, -1, -1, -1, (int)cdx + 1, (int)cdy + 1, (int)cdz + 1, tn, tf, st, (int)(cdx + cdy + cdz) + 10,
+                                   coarse_visit, coarse_post);
             if (st.best_idx != ~0ull) {
                 best_t = st.best;
                 if (WANT_PRIM) {
@@ -783,7 +810,7 @@ void launch_trace(const GridParams& g, const uint32_t cdim[3], const uint32_t* w
     const dim3 grid((unsigned)((nrays + 255) / 256)), block(256);
     const bool want_prim = word_prefix != nullptr;
 #define VX_LAUNCH(P, W) \
-    hipLaunchKernelGGL((k_trace<P, W>), grid, block, 0, s, g, cdim[0], cdim[1], cdim[2], words, cwords, word_prefix, rays, c, nrays, tmin, tmax, t_out, prim_out, hits, nhits)
+    VX_KL((k_trace<P, W>), grid, block, 0, s, g, cdim[0], cdim[1], cdim[2], words, cwords, word_prefix, rays, c, nrays, tmin, tmax, t_out, prim_out, hits, nhits)
     if (cam) { if (want_prim) VX_LAUNCH(true, true); else VX_LAUNCH(true, false); }
     else { if (want_prim) VX_LAUNCH(false, true); else VX_LAUNCH(false, false); }
 #undef VX_LAUNCH

@@ -51,10 +51,36 @@ SYMBOLS = [
     "vx_octree_build", "vx_octree_num_items", "vx_octree_num_nodes", "vx_octree_bytes", "vx_octree_items", "vx_octree_nodes",
     "vx_octree_root_bounds", "vx_octree_aabbs", "vx_octree_aabbs_device", "vx_octree_free",
     "vx_trace", "vx_trace_device", "vx_trace_primary_device",
+    "vx_profile_enable", "vx_profile_reset", "vx_profile_read",
     "vx_shard_words", "vx_shard_range",
 ]
 
 _lib = None
+
+
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's); if
+    libvoxhip.so pulled in the system copy first, a later `import torch` would load a second runtime that sees no GPU.
+    When torch is installed (tests, bench.py: device memory, streams, torch.distributed), bind to ITS runtime by loading
+    it first; plain C/C++ users of libvoxhip.so get the system ROCm runtime via the library's RUNPATH."""
+    if os.environ.get("VOXHIP_SYSTEM_HIP_RUNTIME") == "1":
+        return
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
 
 
 def lib():
@@ -63,6 +89,7 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise ImportError("libvoxhip.so is not built (%s): run __graft_entry__.build(); there is no CPU fallback" % LIB_PATH)
+    _preload_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, u64p, fp, u32p = C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_float), C.POINTER(C.c_uint32)
     L.vx_last_error.restype = C.c_char_p
@@ -116,6 +143,8 @@ def lib():
     L.vx_trace.argtypes = [vp, vp, C.c_uint64, C.c_float, C.c_float, vp, vp, u64p]
     L.vx_trace_device.argtypes = [vp, vp, C.c_uint64, C.c_float, C.c_float, vp, vp, vp, vp]
     L.vx_trace_primary_device.argtypes = [vp, fp, fp, C.c_uint32, C.c_uint32, C.c_float, C.c_float, vp, vp]
+    L.vx_profile_enable.argtypes = [C.c_int]
+    L.vx_profile_read.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), u64p]
     L.vx_shard_words.argtypes = [C.c_uint64, C.c_int, C.c_int, u64p, u64p, u64p]
     L.vx_shard_words.restype = None
     L.vx_shard_range.argtypes = [C.c_uint64, C.c_int, C.c_int, u64p, u64p]
@@ -135,6 +164,30 @@ def device_count():
 
 def set_device(d):
     _check(lib().vx_set_device(d))
+
+
+def profile_enable(on=True):
+    lib().vx_profile_enable(1 if on else 0)
+
+
+def profile_reset():
+    lib().vx_profile_reset()
+
+
+def profile_read():
+    """{kernel base name: (total_ms, launches)} accumulated since the last reset (template arguments folded)."""
+    out = {}
+    slot = 0
+    while True:
+        name = C.create_string_buffer(128)
+        ms, n = C.c_double(), C.c_uint64()
+        if lib().vx_profile_read(slot, name, 128, C.byref(ms), C.byref(n)) != VX_OK:
+            break
+        key = name.value.decode().lstrip("(").split("<")[0].rstrip(")")
+        a, b = out.get(key, (0.0, 0))
+        out[key] = (a + ms.value, b + n.value)
+        slot += 1
+    return out
 
 
 def shard_words(num_words, rank, world):

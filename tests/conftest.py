@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:  # one HIP runtime per process: torch's bundled runtime must be the first one loaded (see voxhip._preload_torch_hip_runtime)
+    import torch  # noqa: F401
+except ImportError:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "raytracing-voxilizer-vulkan-intresection_amd")
 for p in (ROOT, PKG, os.path.join(ROOT, "oracle")):

@@ -245,7 +245,8 @@ def check_trace(vx, g, oa, rays, tmin=0.001, tmax=10000.0):
     ot, op = oracle.trace_brute(oa, rays, tmin, tmax)
     bad = np.flatnonzero((t > 0) != (ot > 0))
     assert bad.size == 0, "hit/miss mismatch on rays %s: gpu %s oracle %s" % (bad[:5], t[bad[:5]], ot[bad[:5]])
-    assert np.allclose(t, ot, rtol=0, atol=1e-5)                    # the north-star tolerance
+    far = np.flatnonzero(np.abs(t - ot) > 1e-5)
+    assert far.size == 0, "t off by > 1e-5 on %d rays, e.g. %s: gpu %s oracle %s rays %s" % (far.size, far[:4], t[far[:4]], ot[far[:4]], rays[far[:2]])
     assert np.array_equal(t, ot), "t not bit-equal (max diff %g)" % np.abs(t - ot).max()
     assert np.array_equal(p, op)
     assert nh == int((ot > 0).sum())
