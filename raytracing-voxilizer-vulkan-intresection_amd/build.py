@@ -18,7 +18,7 @@ ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
          "--offload-arch=" + ARCH]
 
-SOURCES = ["vx_kernels.hip", "vx_sort.hip", "vx_api.cpp", "vx_obj.cpp", "vx_prof.cpp"]
+SOURCES = ["vx_kernels.hip", "vx_trace.hip", "vx_sort.hip", "vx_api.cpp", "vx_obj.cpp", "vx_prof.cpp"]
 HEADERS = ["vx_math.h", "vx_internal.h", os.path.join(ROOT, "include", "voxhip.h")]
 
 

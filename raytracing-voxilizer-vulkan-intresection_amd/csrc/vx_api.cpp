@@ -168,19 +168,19 @@ struct vx_grid {
     vx::GridParams g{};
     float bbmin[3] = {0, 0, 0}, bbmax[3] = {0, 0, 0}, bbc[3] = {0, 0, 0};
     uint64_t triangles = 0;
-    uint32_t cdim[3] = {0, 0, 0};
-    DevBuf words, cwords, wprefix, recs, units, ubase, umask, hbase, scantmp, small, vec;
+    uint32_t cdim[3] = {0, 0, 0}, c2dim[3] = {0, 0, 0};
+    DevBuf words, cwords, c2words, bricks, wprefix, recs, units, ubase, umask, hbase, scantmp, small, vec;
     bool coarse_valid = false, prefix_valid = false, counts_valid = true;
     uint64_t occupied = 0, set_calls = 0, host_set_calls = 0;
     uint64_t vec_count = 0;
     void set_dev(int d)
     {
         device = d;
-        for (DevBuf* b : {&words, &cwords, &wprefix, &recs, &units, &ubase, &umask, &hbase, &scantmp, &small, &vec}) b->dev = d;
+        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &wprefix, &recs, &units, &ubase, &umask, &hbase, &scantmp, &small, &vec}) b->dev = d;
     }
     void release_all()
     {
-        for (DevBuf* b : {&words, &cwords, &wprefix, &recs, &units, &ubase, &umask, &hbase, &scantmp, &small, &vec}) b->release();
+        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &wprefix, &recs, &units, &ubase, &umask, &hbase, &scantmp, &small, &vec}) b->release();
     }
 };
 
@@ -295,10 +295,18 @@ vx_status ensure_coarse(vx_grid* g)
 {
     if (g->coarse_valid) return VX_OK;
     DeviceGuard dg(g->device);
-    for (int a = 0; a < 3; ++a) g->cdim[a] = (g->g.dim[a] + vx::kCoarse - 1) / vx::kCoarse;
+    for (int a = 0; a < 3; ++a) {
+        g->cdim[a] = (g->g.dim[a] + vx::kCoarse - 1) / vx::kCoarse;
+        g->c2dim[a] = (g->cdim[a] + vx::kCoarse - 1) / vx::kCoarse;
+    }
     const uint64_t nc = (uint64_t)g->cdim[0] * g->cdim[1] * g->cdim[2];
-    VX_HIP(g->cwords.ensure((size_t)((nc + 31) / 32 + 1) * 4));
-    vx::launch_build_coarse(g->words.as<uint32_t>(), g->g, g->cdim, g->cwords.as<uint32_t>(), g->stream);
+    const uint64_t nc2 = (uint64_t)g->c2dim[0] * g->c2dim[1] * g->c2dim[2];
+    VX_HIP(g->cwords.ensure((size_t)((nc + 31) / 32 + 2) * 4));
+    VX_HIP(g->c2words.ensure((size_t)((nc2 + 31) / 32 + 2) * 4));
+    vx::launch_build_coarse(g->words.as<uint32_t>(), g->g.dim, g->cdim, g->cwords.as<uint32_t>(), g->stream);
+    vx::launch_build_coarse(g->cwords.as<uint32_t>(), g->cdim, g->c2dim, g->c2words.as<uint32_t>(), g->stream);
+    VX_HIP(g->bricks.ensure((size_t)(nc * 8 + 8) * 8));
+    vx::launch_build_bricks(g->words.as<uint32_t>(), g->g.dim, g->cdim, g->bricks.as<unsigned long long>(), g->stream);
     g->coarse_valid = true;
     return VX_OK;
 }
@@ -734,8 +742,14 @@ static vx_status trace_common(vx_grid* g, const float* dev_rays, const vx::Camer
     VX_TRY(ensure_coarse(g));
     const uint32_t* prefix = nullptr;
     if (dev_prim || dev_hits) { VX_TRY(ensure_prefix(g)); prefix = g->wprefix.as<uint32_t>(); }
-    vx::launch_trace(g->g, g->cdim, g->words.as<uint32_t>(), g->cwords.as<uint32_t>(), prefix, dev_rays, cam, nrays, tmin, tmax, dev_t, dev_prim,
-                     dev_hits, (unsigned long long*)dev_nhits, g->stream);
+    vx::TraceMips mips;
+    mips.bricks = g->bricks.as<unsigned long long>();
+    mips.w0 = g->words.as<uint32_t>();
+    mips.w1 = g->cwords.as<uint32_t>();
+    mips.w2 = g->c2words.as<uint32_t>();
+    for (int a = 0; a < 3; ++a) { mips.d1[a] = g->cdim[a]; mips.d2[a] = g->c2dim[a]; }
+    vx::launch_trace(g->g, mips, prefix, dev_rays, cam, nrays, tmin, tmax, dev_t, dev_prim, dev_hits, (unsigned long long*)dev_nhits,
+                     &g->small.as<Small>()->nhits, g->stream);
     VX_HIP(hipGetLastError());
     return VX_OK;
 }

@@ -67,13 +67,23 @@ void launch_emit_bool_aabbs(const uint32_t* words, const uint32_t* word_prefix, 
 // AABBs from sorted Morton items (Octree::getAabbs)
 void launch_emit_morton_aabbs(const uint64_t* items, uint64_t n, const float root_min[3], float vs, vx_aabb* out, hipStream_t s);
 
-// coarse occupancy mip for the ray kernel
-void launch_build_coarse(const uint32_t* words, const GridParams& g, const uint32_t cdim[3], uint32_t* cwords, hipStream_t s);
+// occupancy mip for the ray kernel: one bit per 8^3 cells of the level below (fdim = dims of that level)
+void launch_build_coarse(const uint32_t* words, const uint32_t fdim[3], const uint32_t cdim[3], uint32_t* cwords, hipStream_t s);
 
-// K6: first hit per ray
-void launch_trace(const GridParams& g, const uint32_t cdim[3], const uint32_t* words, const uint32_t* cwords,
-                  const uint32_t* word_prefix, const float* rays, const Camera* cam, uint64_t nrays, float tmin, float tmax,
-                  float* t_out, uint32_t* prim_out, vx_hit* hits, unsigned long long* nhits, hipStream_t s);
+// K6: first hit per ray.  Three-level occupancy hierarchy: cells (bricks; w0 = the reference-layout bitmask, used for the
+// primitive rank only), 8^3 bricks (w1, dims d1), 64^3 blocks (w2, dims d2).
+void launch_build_bricks(const uint32_t* words, const uint32_t dim[3], const uint32_t bdim[3], unsigned long long* bricks, hipStream_t s);
+struct TraceMips {
+    const unsigned long long* bricks;  // level 0 re-tiled brick-major: one uint64 per (8^3 brick, z slice)
+    const uint32_t* w0;
+    const uint32_t* w1;
+    const uint32_t* w2;
+    uint32_t d1[3];
+    uint32_t d2[3];
+};
+void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* word_prefix, const float* rays, const Camera* cam,
+                  uint64_t nrays, float tmin, float tmax, float* t_out, uint32_t* prim_out, vx_hit* hits, unsigned long long* nhits,
+                  unsigned long long* next_ray /*device work counter*/, hipStream_t s);
 
 // single-voxel helpers
 void launch_set_bit(uint32_t* words, uint64_t idx, hipStream_t s);

@@ -512,11 +512,12 @@ __global__ void k_set_bit(uint32_t* words, uint64_t idx) { atomicOr(&words[idx >
 void launch_set_bit(uint32_t* words, uint64_t idx, hipStream_t s) { VX_KL(k_set_bit, dim3(1), dim3(1), 0, s, words, idx); }
 
 // ------------------------------------------------------------------------------------------------------------
-// Coarse occupancy mip (8^3 fine cells per coarse cell) for empty-space skipping in K6.
+// Occupancy mip (one bit per 8^3 cells of the level below) for empty-space skipping in K6 (vx_trace.hip).
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_build_coarse(const uint32_t* __restrict__ words, GridParams g, uint32_t cx, uint32_t cy, uint32_t cz,
-                                                      uint32_t* __restrict__ cwords)
+__global__ __launch_bounds__(256) void k_build_coarse(const uint32_t* __restrict__ words, uint32_t fx, uint32_t fy, uint32_t fz, uint32_t cx,
+                                                      uint32_t cy, uint32_t cz, uint32_t* __restrict__ cwords)
 {
+    struct { uint32_t dim[3]; } g = {{fx, fy, fz}};
     const uint64_t ncoarse = (uint64_t)cx * cy * cz;
     for (uint64_t c = (uint64_t)blockIdx.x * 256u + threadIdx.x; c < ncoarse; c += (uint64_t)gridDim.x * 256u) {
         const uint32_t kz = (uint32_t)(c / ((uint64_t)cx * cy));
@@ -543,277 +544,12 @@ __global__ __launch_bounds__(256) void k_build_coarse(const uint32_t* __restrict
     }
 }
 
-void launch_build_coarse(const uint32_t* words, const GridParams& g, const uint32_t cdim[3], uint32_t* cwords, hipStream_t s)
+void launch_build_coarse(const uint32_t* words, const uint32_t fdim[3], const uint32_t cdim[3], uint32_t* cwords, hipStream_t s)
 {
     const uint64_t nc = (uint64_t)cdim[0] * cdim[1] * cdim[2];
     if (!nc) return;
     hipMemsetAsync(cwords, 0, (size_t)((nc + 31) / 32) * 4, s);
-    VX_KL(k_build_coarse, dim3(grid_for(nc, 256, kMaxBlocks)), dim3(256), 0, s, words, g, cdim[0], cdim[1], cdim[2], cwords);
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// K6  first hit per ray.
-//
-// The reference hands the occupied voxels' AABBs to the driver's BVH and runs raytrace.rint on every candidate; the
-// result per ray is min over ALL boxes of t0 = hitAabb(box) subject to t0 > 0 (rint:69) and tmin <= t0 <= tmax.
-// Here the occupancy bitmask itself is the acceleration structure: a two-level 3D-DDA (8^3-cell bricks over a coarse
-// mip, then cells) enumerates a SUPERSET of the cells the ray can touch, and every occupied visited cell is put
-// through the exact rint formula on the exact float box the reference would have built for it, so the reported t is
-// the same float the brute-force minimum yields.
-//
-// Conservative enumeration: a cell's float box differs from the nominal lattice planes by a few ulps of the largest
-// coordinate, so whenever two plane crossings are closer in t than that tolerance (per axis: tau = tol_pos*|1/d|)
-// the cells on the other side of the near-tie are probed as well, both forward (next planes) and backward (planes
-// just crossed).  Traversal stops once the entry time of the current cell exceeds the best hit by more than tau.
-// ------------------------------------------------------------------------------------------------------------
-struct RayCtx {
-    float ox, oy, oz, dx, dy, dz, ix, iy, iz;  // origin, direction, 1/direction
-    float taux, tauy, tauz;                    // crossing-time tolerance per axis
-    int sx, sy, sz;                            // step direction (+1/-1)
-};
-
-struct TraceState {
-    float best;
-    uint64_t best_idx;
-};
-
-__device__ __forceinline__ float plane_t(float org, float vs, float o, float inv, int fine_index) { return ((org + (float)fine_index * vs) - o) * inv; }
-
-// Generic DDA over cells of edge (1<<S) fine cells.  The walk itself (the cells the nominal ray passes through) is
-// restricted to cell indices [lo, hi), which may reach outside the grid; VISIT(cx,cy,cz) is called for the walk's
-// current cell and for every near-tie neighbour -- neighbours are NOT restricted to [lo, hi) (a neighbour is a cell the
-// nominal ray does not pass through, so it cannot be walked, only looked at) and the visitor bounds-checks against the
-// grid.  POST(cx,cy,cz,t_in,t_out) runs once per step after the visits.
-template <int S, class Visit, class Post>
-__device__ __forceinline__ void dda_walk(const RayCtx& R, const GridParams& g, int lox, int loy, int loz, int hix, int hiy, int hiz, float t_lo,
-                                         float t_hi, const TraceState& st, int max_iter, Visit&& visit, Post&& post)
-{
-    const float tauS = R.taux + R.tauy + R.tauz;
-    int cx, cy, cz;
-    float tMx, tMy, tMz, tPx, tPy, tPz;
-#define VX_INIT_AXIS(c, tM, tP, o, d, inv, stp, org, lo, hi)                                  \
-    {                                                                                          \
-        const float p = (o) + t_lo * (d);                                                      \
-        int fi = (int)floorf((p - (org)) / g.vs);                                              \
-        int ci = fi >> S;                                                                      \
-        ci = ci < (lo) ? (lo) : ci;                                                            \
-        ci = ci > (hi)-1 ? (hi)-1 : ci;                                                        \
-        c = ci;                                                                                \
-        if ((d) == 0.0f) { tM = INFINITY; tP = -INFINITY; }                                    \
-        else {                                                                                 \
-            tM = plane_t(org, g.vs, o, inv, (ci + ((stp) > 0 ? 1 : 0)) * (1 << S));                  \
-            tP = plane_t(org, g.vs, o, inv, (ci + ((stp) > 0 ? 0 : 1)) * (1 << S));                  \
-        }                                                                                      \
-    }
-    VX_INIT_AXIS(cx, tMx, tPx, R.ox, R.dx, R.ix, R.sx, g.org[0], lox, hix)
-    VX_INIT_AXIS(cy, tMy, tPy, R.oy, R.dy, R.iy, R.sy, g.org[1], loy, hiy)
-    VX_INIT_AXIS(cz, tMz, tPz, R.oz, R.dz, R.iz, R.sz, g.org[2], loz, hiz)
-#undef VX_INIT_AXIS
-    float t_in = t_lo;
-    int entry = -1;  // axis through which the current cell was entered
-    for (int it = 0; it < max_iter; ++it) {
-        const bool ex = (tMx <= tMy) && (tMx <= tMz);
-        const bool ey = !ex && (tMy <= tMz);
-        const bool ez = !ex && !ey;
-        const float t_out = ex ? tMx : (ey ? tMy : tMz);
-        const float tau_exit = ex ? R.taux : (ey ? R.tauy : R.tauz);
-        const float tau_entry = entry == 0 ? R.taux : (entry == 1 ? R.tauy : (entry == 2 ? R.tauz : 0.0f));
-        // forward near-ties (other axes' next planes), backward near-ties (planes just behind)
-        const bool fx = !ex && (tMx - t_out <= tau_exit + R.taux);
-        const bool fy = !ey && (tMy - t_out <= tau_exit + R.tauy);
-        const bool fz = !ez && (tMz - t_out <= tau_exit + R.tauz);
-        const bool bx = entry != 0 && (t_in - tPx <= R.taux + (entry < 0 ? R.taux : tau_entry));
-        const bool by = entry != 1 && (t_in - tPy <= R.tauy + (entry < 0 ? R.tauy : tau_entry));
-        const bool bz = entry != 2 && (t_in - tPz <= R.tauz + (entry < 0 ? R.tauz : tau_entry));
-        const bool any = fx | fy | fz | bx | by | bz;
-        const int ncomb = any ? 27 : 1;
-        for (int j = 0; j < ncomb; ++j) {
-            const int jx = j % 3, jy = (j / 3) % 3, jz = j / 9;  // 0: stay, 1: forward, 2: backward
-            const bool okx = jx == 0 || (jx == 1 ? fx : bx);
-            const bool oky = jy == 0 || (jy == 1 ? fy : by);
-            const bool okz = jz == 0 || (jz == 1 ? fz : bz);
-            if (!(okx && oky && okz)) continue;
-            const int nx = cx + (jx == 0 ? 0 : (jx == 1 ? R.sx : -R.sx));
-            const int ny = cy + (jy == 0 ? 0 : (jy == 1 ? R.sy : -R.sy));
-            const int nz = cz + (jz == 0 ? 0 : (jz == 1 ? R.sz : -R.sz));
-            visit(nx, ny, nz);
-        }
-        post(cx, cy, cz, t_in, t_out);
-        const float lim = fminf(t_hi, st.best + tauS);
-        if (!(t_out <= lim)) break;
-        if (ex) {
-            cx += R.sx;
-            if (cx < lox || cx >= hix) break;
-            tPx = tMx;
-            tMx = plane_t(g.org[0], g.vs, R.ox, R.ix, (cx + (R.sx > 0 ? 1 : 0)) * (1 << S));
-            entry = 0;
-        } else if (ey) {
-            cy += R.sy;
-            if (cy < loy || cy >= hiy) break;
-            tPy = tMy;
-            tMy = plane_t(g.org[1], g.vs, R.oy, R.iy, (cy + (R.sy > 0 ? 1 : 0)) * (1 << S));
-            entry = 1;
-        } else {
-            cz += R.sz;
-            if (cz < loz || cz >= hiz) break;
-            tPz = tMz;
-            tMz = plane_t(g.org[2], g.vs, R.oz, R.iz, (cz + (R.sz > 0 ? 1 : 0)) * (1 << S));
-            entry = 2;
-        }
-        t_in = t_out;
-    }
-}
-
-template <bool PRIMARY, bool WANT_PRIM>
-__global__ __launch_bounds__(256) void k_trace(GridParams g, uint32_t cdx, uint32_t cdy, uint32_t cdz, const uint32_t* __restrict__ words,
-                                               const uint32_t* __restrict__ cwords, const uint32_t* __restrict__ word_prefix,
-                                               const float* __restrict__ rays, Camera cam, uint64_t nrays, float tmin, float tmax,
-                                               float* __restrict__ t_out, uint32_t* __restrict__ prim_out, vx_hit* __restrict__ hits,
-                                               unsigned long long* nhits)
-{
-    const uint64_t r = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    const bool active = r < nrays;
-    float best_t = -1.0f;
-    uint32_t best_prim = 0xFFFFFFFFu;
-    if (active) {
-        RayCtx R;
-        if (PRIMARY) {
-            // raytrace.rgen:41-47; mat*vec in glm's association (m0*v0 + m1*v1) + (m2*v2 + m3*v3)
-            const uint32_t px = (uint32_t)(r % cam.width), py = (uint32_t)(r / cam.width);
-            const float u = ((float)px + 0.5f) / (float)cam.width, v = ((float)py + 0.5f) / (float)cam.height;
-            const float ndx = u * 2.0f - 1.0f, ndy = v * 2.0f - 1.0f;
-            float tg[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-                tg[k] = (cam.projInv[0 + k] * ndx + cam.projInv[4 + k] * ndy) + (cam.projInv[8 + k] * 1.0f + cam.projInv[12 + k] * 1.0f);
-            const float il = 1.0f / sqrtf((tg[0] * tg[0] + tg[1] * tg[1]) + tg[2] * tg[2]);
-            const float n0 = tg[0] * il, n1 = tg[1] * il, n2 = tg[2] * il;
-            R.ox = cam.viewInv[12]; R.oy = cam.viewInv[13]; R.oz = cam.viewInv[14];
-            R.dx = (cam.viewInv[0] * n0 + cam.viewInv[4] * n1) + cam.viewInv[8] * n2;
-            R.dy = (cam.viewInv[1] * n0 + cam.viewInv[5] * n1) + cam.viewInv[9] * n2;
-            R.dz = (cam.viewInv[2] * n0 + cam.viewInv[6] * n1) + cam.viewInv[10] * n2;
-        } else {
-            const float2* rp = reinterpret_cast<const float2*>(rays + 6 * r);
-            const float2 a = rp[0], b = rp[1], c = rp[2];
-            R.ox = a.x; R.oy = a.y; R.oz = b.x; R.dx = b.y; R.dy = c.x; R.dz = c.y;
-        }
-        R.ix = 1.0f / R.dx; R.iy = 1.0f / R.dy; R.iz = 1.0f / R.dz;  // rint:48
-        R.sx = R.dx < 0.0f ? -1 : 1; R.sy = R.dy < 0.0f ? -1 : 1; R.sz = R.dz < 0.0f ? -1 : 1;
-        const float hx = g.org[0] + (float)g.dim[0] * g.vs, hy = g.org[1] + (float)g.dim[1] * g.vs, hz = g.org[2] + (float)g.dim[2] * g.vs;
-        float M = fmaxf(fmaxf(fabsf(R.ox), fabsf(R.oy)), fabsf(R.oz));
-        M = fmaxf(M, fmaxf(fmaxf(fabsf(g.org[0]), fabsf(g.org[1])), fabsf(g.org[2])));
-        M = fmaxf(M, fmaxf(fmaxf(fabsf(hx), fabsf(hy)), fabsf(hz)));
-        const float tolp = M * 9.5367431640625e-07f;  // 16 * 2^-24 * M: covers the <=3-ulp box-plane rounding plus our own
-        R.taux = R.dx == 0.0f ? 0.0f : tolp * fabsf(R.ix);
-        R.tauy = R.dy == 0.0f ? 0.0f : tolp * fabsf(R.iy);
-        R.tauz = R.dz == 0.0f ? 0.0f : tolp * fabsf(R.iz);
-        // entry/exit of the (slightly dilated) grid box
-        float tn = 0.0f, tf = tmax;
-        bool miss = false;
-#define VX_CLIP(o, d, inv, lo, hi)                                                        \
-    if ((d) == 0.0f) { miss |= ((o) < (lo)-tolp) || ((o) > (hi) + tolp); }                 \
-    else {                                                                                 \
-        const float t1 = (((lo)-tolp) - (o)) * (inv), t2 = (((hi) + tolp) - (o)) * (inv);  \
-        tn = fmaxf(tn, fminf(t1, t2));                                                     \
-        tf = fminf(tf, fmaxf(t1, t2));                                                     \
-    }
-        VX_CLIP(R.ox, R.dx, R.ix, g.org[0], hx)
-        VX_CLIP(R.oy, R.dy, R.iy, g.org[1], hy)
-        VX_CLIP(R.oz, R.dz, R.iz, g.org[2], hz)
-#undef VX_CLIP
-        const float tauS = R.taux + R.tauy + R.tauz;
-        tf += tauS;
-        if (!miss && tn <= tf && g.nvox) {
-            TraceState st;
-            st.best = INFINITY;
-            st.best_idx = ~0ull;
-            const float o3[3] = {R.ox, R.oy, R.oz}, inv3[3] = {R.ix, R.iy, R.iz};
-            const uint64_t X = g.dim[0], XY = (uint64_t)g.dim[0] * g.dim[1];
-            auto test_cell = [&](int x, int y, int z) {
-                if ((unsigned)x >= g.dim[0] || (unsigned)y >= g.dim[1] || (unsigned)z >= g.dim[2]) return;
-                const uint64_t i = (uint64_t)x + X * (uint64_t)y + XY * (uint64_t)z;
-                const uint32_t wv = words[i >> 5];
-                if (!((wv >> (i & 31)) & 1u)) return;
-                float bb[6];
-                cell_aabb(g, (uint32_t)x, (uint32_t)y, (uint32_t)z, bb);
-                const float t = hit_aabb(bb, o3, inv3);                       // rint:46-56
-                if (t > 0.0f && t >= tmin && t <= tmax &&                     // rint:69, rgen:50-51
-                    (t < st.best || (t == st.best && i < st.best_idx))) {
-                    st.best = t;
-                    st.best_idx = i;
-                }
-            };
-            auto no_post = [](int, int, int, float, float) {};
-            // coarse level: a brick is refined when it or any near-tie neighbour brick holds an occupied cell; the fine
-            // walk always covers the NOMINAL brick (the one the ray passes through) and reaches the neighbours' cells
-            // through its own near-tie probes.
-            bool occ = false;
-            auto coarse_visit = [&](int kx, int ky, int kz) {
-                if ((unsigned)kx >= cdx || (unsigned)ky >= cdy || (unsigned)kz >= cdz) return;
-                const uint64_t c = (uint64_t)kx + (uint64_t)cdx * ((uint64_t)ky + (uint64_t)cdy * kz);
-                occ |= ((cwords[c >> 5] >> (c & 31)) & 1u) != 0u;
-            };
-            auto coarse_post = [&](int kx, int ky, int kz, float t_in, float) {
-                if (!occ) return;
-                occ = false;
-                const int lx = kx << kCoarseShift, ly = ky << kCoarseShift, lz = kz << kCoarseShift;
-                // start exactly at the brick's entry time (a time slack would slide the start point along the ray's major
-                // axis); the start cell's own rounding is covered by the walk's backward/forward probes; the walk ends
-                // when it leaves the brick.
-                dda_walk<0>(R, g, lx, ly, lz, lx + (int)kCoarse, ly + (int)kCoarse, lz + (int)kCoarse, fmaxf(t_in, tn), INFINITY, st,
-                            3 * (int)kCoarse + 4, test_cell, no_post);
-            };
-            // one virtual coarse cell of halo around the grid: a ray sliding along the outside of a boundary face within
-            // tolerance still walks next to the boundary bricks and probes into them
-            dda_walk<kCoarseShift>(R, g, -1, -1, -1, (int)cdx + 1, (int)cdy + 1, (int)cdz + 1, tn, tf, st, (int)(cdx + cdy + cdz) + 10,
-                                   coarse_visit, coarse_post);
-            if (st.best_idx != ~0ull) {
-                best_t = st.best;
-                if (WANT_PRIM) {
-                    const uint64_t wi = st.best_idx >> 5;
-                    const uint32_t bit = (uint32_t)st.best_idx & 31u;
-                    best_prim = word_prefix[wi] + __popc(words[wi] & ((1u << bit) - 1u));  // rank == gl_PrimitiveID
-                } else
-                    best_prim = 0;
-            }
-        }
-        if (t_out) t_out[r] = best_t;
-        if (WANT_PRIM && prim_out) prim_out[r] = best_prim;
-    }
-    if (hits) {
-        // wavefront hit compaction: ballot + prefix popcount, one atomic per wave
-        const bool hit = active && best_t > 0.0f;
-        const unsigned long long bal = __ballot(hit);
-        if (bal) {
-            const int lane = threadIdx.x & 63;
-            unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(nhits, (unsigned long long)__popcll(bal));
-            base = ((unsigned long long)__shfl((unsigned)(base >> 32), 0, 64) << 32) | __shfl((unsigned)base, 0, 64);
-            if (hit) {
-                const unsigned pre = __popcll(bal & ((1ull << lane) - 1ull));
-                vx_hit h;
-                h.ray = (uint32_t)r; h.prim = best_prim; h.t = best_t;
-                hits[base + pre] = h;
-            }
-        }
-    }
-}
-
-void launch_trace(const GridParams& g, const uint32_t cdim[3], const uint32_t* words, const uint32_t* cwords, const uint32_t* word_prefix,
-                  const float* rays, const Camera* cam, uint64_t nrays, float tmin, float tmax, float* t_out, uint32_t* prim_out,
-                  vx_hit* hits, unsigned long long* nhits, hipStream_t s)
-{
-    if (!nrays) return;
-    if (hits && nhits) hipMemsetAsync(nhits, 0, sizeof(unsigned long long), s);
-    Camera c{};
-    if (cam) c = *cam;
-    const dim3 grid((unsigned)((nrays + 255) / 256)), block(256);
-    const bool want_prim = word_prefix != nullptr;
-#define VX_LAUNCH(P, W) \
-    VX_KL((k_trace<P, W>), grid, block, 0, s, g, cdim[0], cdim[1], cdim[2], words, cwords, word_prefix, rays, c, nrays, tmin, tmax, t_out, prim_out, hits, nhits)
-    if (cam) { if (want_prim) VX_LAUNCH(true, true); else VX_LAUNCH(true, false); }
-    else { if (want_prim) VX_LAUNCH(false, true); else VX_LAUNCH(false, false); }
-#undef VX_LAUNCH
+    VX_KL(k_build_coarse, dim3(grid_for(nc, 256, kMaxBlocks)), dim3(256), 0, s, words, fdim[0], fdim[1], fdim[2], cdim[0], cdim[1], cdim[2], cwords);
 }
 
 }  // namespace vx

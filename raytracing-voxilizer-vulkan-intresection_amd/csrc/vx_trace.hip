@@ -1,0 +1,472 @@
+// vx_trace.hip -- K6: first hit per ray against the occupied voxels' AABBs (replaces the procedural-hit stage
+// raytrace.rint:46-71 that the reference runs under traceRayEXT, raytrace.rgen:49-64).
+//
+// The reference hands the occupied voxels' AABBs to the driver's BVH and runs raytrace.rint on every candidate; the result
+// per ray is the minimum over ALL boxes of t0 = hitAabb(box) subject to t0 > 0 (rint:69) and tmin <= t0 <= tmax.  Here the
+// occupancy itself is the acceleration structure: a 3-level 3D-DDA (64^3-cell blocks, 8^3-cell bricks, cells) enumerates a
+// SUPERSET of the cells the ray can touch, and every occupied visited cell is put through the exact rint formula on the
+// exact float box the reference would have built for it -- so the reported t is the very float the brute-force minimum
+// yields.
+//
+// Data layout for traversal (built once per grid by k_build_bricks / k_build_coarse, the analogue of the reference's BLAS
+// build, hello_vulkan.cpp:737-760):
+//   level 0  "bricks": the bitmask re-tiled brick-major -- one uint64 per (8x8x8 brick, z slice), bit = (y&7)*8 + (x&7).  A
+//            lane keeps the slice it is walking in two registers, so a whole slice of cells costs ONE dependent 8-byte load
+//            instead of one load per cell (the kernel is latency-bound: measured 47 % of wave cycles in s_waitcnt with the
+//            reference-layout bitmask).
+//   level 1  one bit per brick, x-fastest; staged in LDS by every workgroup when it fits (32 KiB at 512^3).
+//   level 2  one bit per 8^3 bricks; a few hundred bytes, read through L1/L2.
+//
+// Conservative enumeration.  A cell's float box differs from the nominal lattice planes by a few ulps of the largest
+// coordinate.  Whenever two plane crossings are closer in t than that tolerance (per axis tau = tol_pos * |1/d|) the cells
+// on the other side of the near-tie are LOOKED AT as well, forward (the other axes' next planes) and backward (planes just
+// crossed).  Such neighbours are never walked -- the nominal ray does not pass through them -- only tested (level 0) or
+// OR-ed into the "descend?" decision (upper levels); the walk always descends into the nominal cell and reaches the
+// neighbours' children through the child level's own probes.  Traversal stops once the exit time of the current cell
+// exceeds the best hit by more than the tolerance.
+//
+// Wave efficiency.  One flat loop per lane: every iteration is a single DDA step at the lane's current level (descend /
+// advance / pop; the parent's state is recomputed on pop instead of being kept in registers).  Waves are persistent and
+// lanes whose ray has finished pull the next ray from a global counter, so rays of very different path lengths do not
+// leave most of a wave idle.
+//
+// No MFMA: this is traversal, not a contraction.  Algorithmic HBM traffic is the ray stream (24 B in, 4-8 B out per ray).
+#include "vx_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace vx {
+
+#define VX_KL(kern, grid, block, shmem, stream, ...)                         \
+    do {                                                                     \
+        ProfScope ps_(#kern, stream);                                        \
+        hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__);   \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------------------
+// Brick-major re-tiling of the occupancy bitmask.  One thread per (brick, z slice): gathers 8 rows of 8 bits.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_build_bricks(const uint32_t* __restrict__ words, uint32_t X, uint32_t Y, uint32_t Z, uint32_t BX, uint32_t BY,
+                                                      uint32_t BZ, unsigned long long* __restrict__ bricks)
+{
+    const uint64_t n = (uint64_t)BX * BY * BZ * 8ull;
+    for (uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x; t < n; t += (uint64_t)gridDim.x * 256u) {
+        // consecutive threads: consecutive bricks along x for a fixed slice, so their byte reads fall in the same rows
+        const uint32_t bx = (uint32_t)(t % BX);
+        const uint64_t q = t / BX;
+        const uint32_t s = (uint32_t)(q & 7u);
+        const uint64_t q2 = q >> 3;
+        const uint32_t by = (uint32_t)(q2 % BY), bz = (uint32_t)(q2 / BY);
+        const uint32_t z = bz * 8u + s, x0 = bx * 8u;
+        unsigned long long bits = 0;
+        if (z < Z) {
+            const uint32_t nb = (X - x0) < 8u ? (X - x0) : 8u;
+            for (uint32_t yy = 0; yy < 8u; ++yy) {
+                const uint32_t y = by * 8u + yy;
+                if (y >= Y) break;
+                const uint64_t i0 = (uint64_t)X * ((uint64_t)y + (uint64_t)Y * z) + x0;
+                const uint32_t sh = (uint32_t)i0 & 31u;
+                const uint64_t wi = i0 >> 5;
+                uint32_t val = words[wi] >> sh;
+                if (sh + nb > 32u) val |= words[wi + 1] << (32u - sh);
+                val &= (1u << nb) - 1u;
+                bits |= (unsigned long long)val << (yy * 8u);
+            }
+        }
+        const uint64_t brick = (uint64_t)bx + (uint64_t)BX * ((uint64_t)by + (uint64_t)BY * bz);
+        bricks[brick * 8ull + s] = bits;
+    }
+}
+
+void launch_build_bricks(const uint32_t* words, const uint32_t dim[3], const uint32_t bdim[3], unsigned long long* bricks, hipStream_t s)
+{
+    const uint64_t n = (uint64_t)bdim[0] * bdim[1] * bdim[2] * 8ull;
+    if (!n) return;
+    uint64_t nblk = (n + 255) / 256;
+    if (nblk > 8192) nblk = 8192;
+    VX_KL(k_build_bricks, dim3((unsigned)nblk), dim3(256), 0, s, words, dim[0], dim[1], dim[2], bdim[0], bdim[1], bdim[2], bricks);
+}
+
+namespace {
+
+// everything a lane carries for the ray it is currently tracing
+struct Lane {
+    float ox, oy, oz, dx, dy, dz, ix, iy, iz;  // origin, direction, 1/direction (rint:48)
+    float taux, tauy, tauz;                    // crossing-time tolerance per axis
+    float tn, tf;                              // entry / exit of the dilated grid box
+    float best;                                // best accepted t so far
+    uint64_t best_idx;                         // voxel index of the best hit
+    // DDA state of the current level
+    int cx, cy, cz;                            // current cell (in cells of this level)
+    int px, py, pz;                            // parent cell (walk bounds of this level = its 8^3 children)
+    int emask;                                 // axis through which the current cell was entered: 1 x, 2 y, 4 z, 0 = start cell
+    float tau_ent;                             // tolerance of that axis (bit flags, not an axis index: an index makes the
+                                               // compiler build scratch lookup tables out of the select chains)
+    float tMx, tMy, tMz;                       // time of the next plane crossing per axis
+    float tPx, tPy, tPz;                       // time of the plane behind per axis
+    float t_in;                                // entry time of the current cell
+    int lvl;
+    bool skip_visit;
+    // level-0 slice cache
+    uint32_t ckey;
+    unsigned long long cbits;
+};
+
+// Axis selection BY VALUE.  `c ? R.x : R.y` on two struct members is an lvalue conditional: clang selects the ADDRESS and
+// loads afterwards, which kept the lane state in scratch memory (dynamic scratch_load per step).  Passing the operands by
+// value forces the loads first and the select stays in registers.
+__device__ __forceinline__ float sel3(bool a, bool b, float x, float y, float z) { return a ? x : (b ? y : z); }
+__device__ __forceinline__ int sel3(bool a, bool b, int x, int y, int z) { return a ? x : (b ? y : z); }
+
+__device__ __forceinline__ float plane_t(float org, float vs, float o, float inv, int fine_index) { return ((org + (float)fine_index * vs) - o) * inv; }
+
+// next / previous plane times of cell ci (cells of edge 1<<sh) along one axis
+__device__ __forceinline__ void axis_planes(float& tM, float& tP, int ci, float o, float d, float inv, float org, float vs, int sh)
+{
+    const int scale = 1 << sh;
+    const float a = plane_t(org, vs, o, inv, (ci + 1) * scale), b = plane_t(org, vs, o, inv, ci * scale);
+    const bool pos = d >= 0.0f;
+    tM = d == 0.0f ? INFINITY : (pos ? a : b);
+    tP = d == 0.0f ? -INFINITY : (pos ? b : a);
+}
+
+__device__ __forceinline__ int start_cell(float o, float d, float org, float inv_vs, int sh, int lo, int hi, float t_lo)
+{
+    // the probes cover the start cell's rounding, so a reciprocal multiply is enough here
+    const float p = o + t_lo * d;
+    int ci = ((int)floorf((p - org) * inv_vs)) >> sh;
+    ci = ci < lo ? lo : ci;
+    return ci > hi - 1 ? hi - 1 : ci;
+}
+
+// enter level (sh = 3*level) inside walk bounds [lo, hi) at time t_lo
+__device__ __forceinline__ void enter_level(Lane& R, const GridParams& g, float inv_vs, int sh, int lox, int loy, int loz, int hix, int hiy, int hiz,
+                                            float t_lo)
+{
+    R.cx = start_cell(R.ox, R.dx, g.org[0], inv_vs, sh, lox, hix, t_lo);
+    R.cy = start_cell(R.oy, R.dy, g.org[1], inv_vs, sh, loy, hiy, t_lo);
+    R.cz = start_cell(R.oz, R.dz, g.org[2], inv_vs, sh, loz, hiz, t_lo);
+    axis_planes(R.tMx, R.tPx, R.cx, R.ox, R.dx, R.ix, g.org[0], g.vs, sh);
+    axis_planes(R.tMy, R.tPy, R.cy, R.oy, R.dy, R.iy, g.org[1], g.vs, sh);
+    axis_planes(R.tMz, R.tPz, R.cz, R.oz, R.dz, R.iz, g.org[2], g.vs, sh);
+    R.t_in = t_lo;
+    R.emask = 0;
+    R.tau_ent = 0.0f;
+}
+
+// Ray set-up: tolerances, grid clip, top-level start.  Returns false when the ray cannot touch the grid.
+__device__ __forceinline__ bool setup_ray(Lane& R, const GridParams& g, const TraceMips& M, float inv_vs, float tmax)
+{
+    R.ix = 1.0f / R.dx; R.iy = 1.0f / R.dy; R.iz = 1.0f / R.dz;  // rint:48
+    const float hx = g.org[0] + (float)g.dim[0] * g.vs, hy = g.org[1] + (float)g.dim[1] * g.vs, hz = g.org[2] + (float)g.dim[2] * g.vs;
+    float Mx = fmaxf(fmaxf(fabsf(R.ox), fabsf(R.oy)), fabsf(R.oz));
+    Mx = fmaxf(Mx, fmaxf(fmaxf(fabsf(g.org[0]), fabsf(g.org[1])), fabsf(g.org[2])));
+    Mx = fmaxf(Mx, fmaxf(fmaxf(fabsf(hx), fabsf(hy)), fabsf(hz)));
+    // position tolerance 16 * 2^-24 * max|coordinate|: the box planes carry <= 3 roundings of grid-sized numbers, the slab
+    // formula subtracts the (possibly far) origin and multiplies by a rounded reciprocal (relative 2^-23 of the distance
+    // travelled), and this kernel's own plane times carry the same again
+    const float tolp = Mx * 9.5367431640625e-07f;
+    R.taux = R.dx == 0.0f ? 0.0f : tolp * fabsf(R.ix);
+    R.tauy = R.dy == 0.0f ? 0.0f : tolp * fabsf(R.iy);
+    R.tauz = R.dz == 0.0f ? 0.0f : tolp * fabsf(R.iz);
+    float tn = 0.0f, tf = tmax;
+    bool miss = false;
+#define VX_CLIP(o, d, inv, lo, hi)                                                        \
+    if ((d) == 0.0f) { miss |= ((o) < (lo)-tolp) || ((o) > (hi) + tolp); }                 \
+    else {                                                                                 \
+        const float t1 = (((lo)-tolp) - (o)) * (inv), t2 = (((hi) + tolp) - (o)) * (inv);  \
+        tn = fmaxf(tn, fminf(t1, t2));                                                     \
+        tf = fminf(tf, fmaxf(t1, t2));                                                     \
+    }
+    VX_CLIP(R.ox, R.dx, R.ix, g.org[0], hx)
+    VX_CLIP(R.oy, R.dy, R.iy, g.org[1], hy)
+    VX_CLIP(R.oz, R.dz, R.iz, g.org[2], hz)
+#undef VX_CLIP
+    tf += R.taux + R.tauy + R.tauz;
+    R.tn = tn;
+    R.tf = tf;
+    R.best = INFINITY;
+    R.best_idx = ~0ull;
+    R.lvl = 2;
+    R.skip_visit = false;
+    R.ckey = 0xFFFFFFFFu;
+    R.cbits = 0ull;
+    R.px = R.py = R.pz = 0;
+    if (miss || !(tn <= tf) || !g.nvox) return false;
+    // one virtual cell of halo around the top level: a ray sliding along the outside of a boundary face within tolerance
+    // still walks next to the boundary cells and probes into them
+    enter_level(R, g, inv_vs, 6, -1, -1, -1, (int)M.d2[0] + 1, (int)M.d2[1] + 1, (int)M.d2[2] + 1, tn);
+    return true;
+}
+
+// One traversal step of the lane's ray at its current level: look at the current cell (and near-tie neighbours), then
+// descend, advance or pop.  Returns false when the ray is finished.
+template <bool LDS_M1>
+__device__ __forceinline__ bool step_ray(Lane& R, const GridParams& g, const TraceMips& M, const uint32_t* __restrict__ m1_lds, float inv_vs, float tmin,
+                                         float tmax)
+{
+    const int lvl = R.lvl;
+    const bool ex = (R.tMx <= R.tMy) && (R.tMx <= R.tMz);
+    const bool ey = !ex && (R.tMy <= R.tMz);
+    const float t_o = sel3(ex, ey, R.tMx, R.tMy, R.tMz);
+    const int sx = R.dx < 0.0f ? -1 : 1, sy = R.dy < 0.0f ? -1 : 1, sz = R.dz < 0.0f ? -1 : 1;
+    const float tauS = R.taux + R.tauy + R.tauz;
+    if (!R.skip_visit) {
+        bool occ = false;
+        auto look = [&](int nx, int ny, int nz) {
+            if (lvl == 0) {
+                if ((unsigned)nx >= g.dim[0] || (unsigned)ny >= g.dim[1] || (unsigned)nz >= g.dim[2]) return;
+                const uint32_t key = (((uint32_t)nx >> 3) + M.d1[0] * (((uint32_t)ny >> 3) + M.d1[1] * ((uint32_t)nz >> 3))) * 8u + ((uint32_t)nz & 7u);
+                if (key != R.ckey) {
+                    R.cbits = M.bricks[key];
+                    R.ckey = key;
+                }
+                if (!((R.cbits >> ((((uint32_t)ny & 7u) << 3) + ((uint32_t)nx & 7u))) & 1ull)) return;
+                float bb[6];
+                cell_aabb(g, (uint32_t)nx, (uint32_t)ny, (uint32_t)nz, bb);
+                const float o3[3] = {R.ox, R.oy, R.oz}, inv3[3] = {R.ix, R.iy, R.iz};
+                const float t = hit_aabb(bb, o3, inv3);                       // rint:46-56
+                const uint64_t i = (uint64_t)nx + (uint64_t)g.dim[0] * ((uint64_t)ny + (uint64_t)g.dim[1] * (uint64_t)nz);
+                if (t > 0.0f && t >= tmin && t <= tmax &&                     // rint:69, rgen:50-51
+                    (t < R.best || (t == R.best && i < R.best_idx))) {
+                    R.best = t;
+                    R.best_idx = i;
+                }
+            } else if (lvl == 1) {
+                if ((unsigned)nx >= M.d1[0] || (unsigned)ny >= M.d1[1] || (unsigned)nz >= M.d1[2]) return;
+                const uint32_t i = (uint32_t)nx + M.d1[0] * ((uint32_t)ny + M.d1[1] * (uint32_t)nz);
+                const uint32_t w = LDS_M1 ? m1_lds[i >> 5] : M.w1[i >> 5];
+                occ |= ((w >> (i & 31u)) & 1u) != 0u;
+            } else {
+                if ((unsigned)nx >= M.d2[0] || (unsigned)ny >= M.d2[1] || (unsigned)nz >= M.d2[2]) return;
+                const uint32_t i = (uint32_t)nx + M.d2[0] * ((uint32_t)ny + M.d2[1] * (uint32_t)nz);
+                occ |= ((M.w2[i >> 5] >> (i & 31u)) & 1u) != 0u;
+            }
+        };
+        look(R.cx, R.cy, R.cz);
+        // forward near-ties (other axes' next planes), backward near-ties (planes just behind)
+        const float tau_exit = sel3(ex, ey, R.taux, R.tauy, R.tauz);
+        const bool start = R.emask == 0;
+        const bool ez = !ex && !ey;
+        const bool fx = !ex && (R.tMx - t_o <= tau_exit + R.taux);
+        const bool fy = !ey && (R.tMy - t_o <= tau_exit + R.tauy);
+        const bool fz = !ez && (R.tMz - t_o <= tau_exit + R.tauz);
+        const bool bx = !(R.emask & 1) && (R.t_in - R.tPx <= R.taux + sel3(start, false, R.taux, 0.0f, R.tau_ent));
+        const bool by = !(R.emask & 2) && (R.t_in - R.tPy <= R.tauy + sel3(start, false, R.tauy, 0.0f, R.tau_ent));
+        const bool bz = !(R.emask & 4) && (R.t_in - R.tPz <= R.tauz + sel3(start, false, R.tauz, 0.0f, R.tau_ent));
+        if (fx | fy | fz | bx | by | bz) {
+            if ((fx & bx) | (fy & by) | (fz & bz)) {
+                // a cell crossed in less than the tolerance: both directions of an axis are in play (very rare)
+                for (int j = 1; j < 27; ++j) {
+                    const int jx = j % 3, jy = (j / 3) % 3, jz = j / 9;  // 0: stay, 1: forward, 2: backward
+                    const bool okx = jx == 0 || (jx == 1 ? fx : bx);
+                    const bool oky = jy == 0 || (jy == 1 ? fy : by);
+                    const bool okz = jz == 0 || (jz == 1 ? fz : bz);
+                    if (!(okx && oky && okz)) continue;
+                    look(R.cx + (jx == 0 ? 0 : (jx == 1 ? sx : -sx)), R.cy + (jy == 0 ? 0 : (jy == 1 ? sy : -sy)),
+                         R.cz + (jz == 0 ? 0 : (jz == 1 ? sz : -sz)));
+                }
+            } else {
+                // one direction per flagged axis: the non-empty subsets of the flagged axes
+                const int ax = fx ? sx : (bx ? -sx : 0), ay = fy ? sy : (by ? -sy : 0), az = fz ? sz : (bz ? -sz : 0);
+                const int fm = (ax != 0 ? 1 : 0) | (ay != 0 ? 2 : 0) | (az != 0 ? 4 : 0);
+                for (int m = 1; m < 8; ++m) {
+                    if (m & ~fm) continue;
+                    look(R.cx + ((m & 1) ? ax : 0), R.cy + ((m & 2) ? ay : 0), R.cz + ((m & 4) ? az : 0));
+                }
+            }
+        }
+        if (occ) {
+            // descend into the NOMINAL cell's children, starting exactly at its entry time (a time slack would slide the
+            // start point along the ray's major axis; the start cell's rounding is covered by the child walk's probes)
+            R.px = R.cx; R.py = R.cy; R.pz = R.cz;
+            const int lx = R.cx * 8, ly = R.cy * 8, lz = R.cz * 8;
+            enter_level(R, g, inv_vs, (lvl - 1) * 3, lx, ly, lz, lx + 8, ly + 8, lz + 8, fmaxf(R.t_in, R.tn));
+            R.lvl = lvl - 1;
+            return true;
+        }
+    }
+    R.skip_visit = false;
+    // nothing at or beyond this cell's exit can beat the best hit / lies inside the grid: done
+    const float lim = fminf(R.tf, R.best + tauS);
+    if (!(t_o <= lim)) return false;
+    // advance along the exit axis (branch-free: select the axis' operands, compute once, write back)
+    const int sh = lvl * 3;
+    const float tau_exit_adv = sel3(ex, ey, R.taux, R.tauy, R.tauz);
+    const float org_a = sel3(ex, ey, g.org[0], g.org[1], g.org[2]);
+    const float o_a = sel3(ex, ey, R.ox, R.oy, R.oz);
+    const float i_a = sel3(ex, ey, R.ix, R.iy, R.iz);
+    const int s_a = sel3(ex, ey, sx, sy, sz);
+    const int c_a = sel3(ex, ey, R.cx, R.cy, R.cz) + s_a;
+    const int p_a = sel3(ex, ey, R.px, R.py, R.pz);
+    const int top_hi = sel3(ex, ey, (int)M.d2[0], (int)M.d2[1], (int)M.d2[2]) + 1;
+    const int lo_a = lvl == 2 ? -1 : p_a * 8;
+    const int hi_a = lvl == 2 ? top_hi : p_a * 8 + 8;
+    const bool out = c_a < lo_a || c_a >= hi_a;
+    const float tM_new = plane_t(org_a, g.vs, o_a, i_a, (c_a + (s_a > 0 ? 1 : 0)) * (1 << sh));
+    if (ex) { R.cx = c_a; R.tPx = R.tMx; R.tMx = tM_new; }
+    else if (ey) { R.cy = c_a; R.tPy = R.tMy; R.tMy = tM_new; }
+    else { R.cz = c_a; R.tPz = R.tMz; R.tMz = tM_new; }
+    R.emask = ex ? 1 : (ey ? 2 : 4);
+    R.tau_ent = tau_exit_adv;
+    R.t_in = t_o;
+    if (out) {
+        // left the parent cell: resume the parent level (its plane times are recomputed, not stored) and let it advance
+        // on the next step
+        if (lvl == 2) return false;
+        const int nl = lvl + 1;
+        R.cx = R.px; R.cy = R.py; R.cz = R.pz;
+        R.px >>= 3; R.py >>= 3; R.pz >>= 3;  // parent of the parent (unused at the top level)
+        axis_planes(R.tMx, R.tPx, R.cx, R.ox, R.dx, R.ix, g.org[0], g.vs, nl * 3);
+        axis_planes(R.tMy, R.tPy, R.cy, R.oy, R.dy, R.iy, g.org[1], g.vs, nl * 3);
+        axis_planes(R.tMz, R.tPz, R.cz, R.oz, R.dz, R.iz, g.org[2], g.vs, nl * 3);
+        R.lvl = nl;
+        R.skip_visit = true;
+    }
+    return true;
+}
+
+}  // namespace
+
+// Persistent waves with dynamic ray fetch.  Exit condition every wave reaches: the counter passes nrays (no refill
+// possible) and every lane's ray has finished; each ray finishes in a bounded number of steps.
+template <bool PRIMARY, bool WANT_PRIM, bool LDS_M1>
+__global__ __launch_bounds__(256) void k_trace(GridParams g, TraceMips M, const uint32_t* __restrict__ word_prefix, const float* __restrict__ rays,
+                                               Camera cam, uint64_t nrays, float tmin, float tmax, float* __restrict__ t_out,
+                                               uint32_t* __restrict__ prim_out, vx_hit* __restrict__ hits, unsigned long long* nhits,
+                                               unsigned long long* next_ray, uint32_t m1_words)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t m1_lds[];
+    if (LDS_M1) {
+        for (uint32_t i = threadIdx.x; i < m1_words; i += 256u) m1_lds[i] = M.w1[i];
+        __syncthreads();
+    }
+    constexpr int kStepsPerRound = 8;   // traversal steps between two refill checks
+    constexpr int kRefillBelow = 44;    // refill when fewer than this many lanes are busy
+    const int lane = threadIdx.x & 63;
+    const float inv_vs = 1.0f / g.vs;
+    Lane R;
+    uint64_t r = ~0ull;      // ray this lane is tracing (~0: none)
+    bool busy = false;       // traversal in progress
+    bool drained = false;    // the global counter is exhausted
+    int steps_left = 0;      // safety cap per ray
+    for (;;) {
+        const unsigned long long busy_mask = __ballot(busy);
+        const int nbusy = __popcll(busy_mask);
+        if (!drained && nbusy < kRefillBelow) {
+            // ---- refill idle lanes
+            const unsigned long long idle_mask = ~busy_mask;
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(next_ray, (unsigned long long)(64 - nbusy));
+            base = ((unsigned long long)__shfl((unsigned)(base >> 32), 0, 64) << 32) | __shfl((unsigned)base, 0, 64);
+            if (base + (unsigned long long)(64 - nbusy) >= nrays) drained = true;
+            if (!busy) {
+                const uint64_t mine = base + __popcll(idle_mask & ((1ull << lane) - 1ull));
+                if (mine < nrays) {
+                    r = mine;
+                    if (PRIMARY) {
+                        // raytrace.rgen:41-47; mat*vec in glm's association (m0*v0 + m1*v1) + (m2*v2 + m3*v3)
+                        const uint32_t px = (uint32_t)(r % cam.width), py = (uint32_t)(r / cam.width);
+                        const float u = ((float)px + 0.5f) / (float)cam.width, v = ((float)py + 0.5f) / (float)cam.height;
+                        const float ndx = u * 2.0f - 1.0f, ndy = v * 2.0f - 1.0f;
+                        float tg[3];
+#pragma unroll
+                        for (int k = 0; k < 3; ++k)
+                            tg[k] = (cam.projInv[0 + k] * ndx + cam.projInv[4 + k] * ndy) + (cam.projInv[8 + k] * 1.0f + cam.projInv[12 + k] * 1.0f);
+                        const float il = 1.0f / sqrtf((tg[0] * tg[0] + tg[1] * tg[1]) + tg[2] * tg[2]);
+                        const float n0 = tg[0] * il, n1 = tg[1] * il, n2 = tg[2] * il;
+                        R.ox = cam.viewInv[12]; R.oy = cam.viewInv[13]; R.oz = cam.viewInv[14];
+                        R.dx = (cam.viewInv[0] * n0 + cam.viewInv[4] * n1) + cam.viewInv[8] * n2;
+                        R.dy = (cam.viewInv[1] * n0 + cam.viewInv[5] * n1) + cam.viewInv[9] * n2;
+                        R.dz = (cam.viewInv[2] * n0 + cam.viewInv[6] * n1) + cam.viewInv[10] * n2;
+                    } else {
+                        const float2* rp = reinterpret_cast<const float2*>(rays + 6 * r);
+                        const float2 a = rp[0], b = rp[1], c = rp[2];
+                        R.ox = a.x; R.oy = a.y; R.oz = b.x; R.dx = b.y; R.dy = c.x; R.dz = c.y;
+                    }
+                    busy = setup_ray(R, g, M, inv_vs, tmax);
+                    steps_left = 1 << 20;
+                    if (!busy) {  // cannot touch the grid: retire at once as a miss
+                        if (t_out) t_out[r] = -1.0f;
+                        if (WANT_PRIM && prim_out) prim_out[r] = 0xFFFFFFFFu;
+                        r = ~0ull;
+                    }
+                }
+            }
+        }
+        if (!__ballot(busy)) {
+            if (drained) break;
+            continue;
+        }
+        // ---- trace
+        bool finished = false;
+        if (busy) {
+#pragma unroll 1
+            for (int k = 0; k < kStepsPerRound; ++k) {
+                if (!step_ray<LDS_M1>(R, g, M, m1_lds, inv_vs, tmin, tmax) || --steps_left <= 0) { finished = true; break; }
+            }
+        }
+        // ---- retire
+        float best_t = -1.0f;
+        uint32_t best_prim = 0xFFFFFFFFu;
+        if (finished) {
+            if (R.best_idx != ~0ull) {
+                best_t = R.best;
+                if (WANT_PRIM) {
+                    const uint64_t wi = R.best_idx >> 5;
+                    const uint32_t bit = (uint32_t)R.best_idx & 31u;
+                    best_prim = word_prefix[wi] + __popc(M.w0[wi] & ((1u << bit) - 1u));  // rank == gl_PrimitiveID
+                } else
+                    best_prim = 0;
+            }
+            if (t_out) t_out[r] = best_t;
+            if (WANT_PRIM && prim_out) prim_out[r] = best_prim;
+            busy = false;
+        }
+        if (hits) {
+            // wavefront hit compaction: ballot + prefix popcount, one atomic per wave and retire event
+            const bool hit = finished && best_t > 0.0f;
+            const unsigned long long bal = __ballot(hit);
+            if (bal) {
+                unsigned long long hb = 0;
+                if (lane == 0) hb = atomicAdd(nhits, (unsigned long long)__popcll(bal));
+                hb = ((unsigned long long)__shfl((unsigned)(hb >> 32), 0, 64) << 32) | __shfl((unsigned)hb, 0, 64);
+                if (hit) {
+                    vx_hit h;
+                    h.ray = (uint32_t)r; h.prim = best_prim; h.t = best_t;
+                    hits[hb + __popcll(bal & ((1ull << lane) - 1ull))] = h;
+                }
+            }
+        }
+        if (finished) r = ~0ull;
+    }
+}
+
+void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* word_prefix, const float* rays, const Camera* cam, uint64_t nrays,
+                  float tmin, float tmax, float* t_out, uint32_t* prim_out, vx_hit* hits, unsigned long long* nhits, unsigned long long* next_ray,
+                  hipStream_t s)
+{
+    if (!nrays) return;
+    if (hits && nhits) hipMemsetAsync(nhits, 0, sizeof(unsigned long long), s);
+    hipMemsetAsync(next_ray, 0, sizeof(unsigned long long), s);
+    Camera c{};
+    if (cam) c = *cam;
+    const uint64_t n1 = (uint64_t)mips.d1[0] * mips.d1[1] * mips.d1[2];
+    const uint32_t m1_words = (uint32_t)((n1 + 31) / 32);
+    const bool lds_m1 = (size_t)m1_words * 4 <= 40960;  // 4 workgroups x 40 KiB fit the CU's 160 KiB
+    // persistent grid: 256 CUs x 4 resident 256-thread workgroups, fewer when there are not that many rays
+    uint64_t nblk = (nrays + 255) / 256;
+    if (nblk > 1024) nblk = 1024;
+    const dim3 grid((unsigned)nblk), block(256);
+    const bool want_prim = word_prefix != nullptr;
+    const size_t shmem = lds_m1 ? (size_t)m1_words * 4 : 0;
+#define VX_LAUNCH(P, W, L) \
+    VX_KL((k_trace<P, W, L>), grid, block, shmem, s, g, mips, word_prefix, rays, c, nrays, tmin, tmax, t_out, prim_out, hits, nhits, next_ray, m1_words)
+#define VX_LAUNCH2(P, W) do { if (lds_m1) VX_LAUNCH(P, W, true); else VX_LAUNCH(P, W, false); } while (0)
+    if (cam) { if (want_prim) VX_LAUNCH2(true, true); else VX_LAUNCH2(true, false); }
+    else { if (want_prim) VX_LAUNCH2(false, true); else VX_LAUNCH2(false, false); }
+#undef VX_LAUNCH2
+#undef VX_LAUNCH
+}
+
+}  // namespace vx
