@@ -169,18 +169,18 @@ struct vx_grid {
     float bbmin[3] = {0, 0, 0}, bbmax[3] = {0, 0, 0}, bbc[3] = {0, 0, 0};
     uint64_t triangles = 0;
     uint32_t cdim[3] = {0, 0, 0}, c2dim[3] = {0, 0, 0};
-    DevBuf words, cwords, c2words, bricks, wprefix, recs, units, ubase, umask, hbase, scantmp, small, vec;
+    DevBuf words, cwords, c2words, bricks, wprefix, recs, units, ubase, btri, umask, hbase, scantmp, small, vec;
     bool coarse_valid = false, prefix_valid = false, counts_valid = true;
     uint64_t occupied = 0, set_calls = 0, host_set_calls = 0;
     uint64_t vec_count = 0;
     void set_dev(int d)
     {
         device = d;
-        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &wprefix, &recs, &units, &ubase, &umask, &hbase, &scantmp, &small, &vec}) b->dev = d;
+        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &wprefix, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec}) b->dev = d;
     }
     void release_all()
     {
-        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &wprefix, &recs, &units, &ubase, &umask, &hbase, &scantmp, &small, &vec}) b->release();
+        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &wprefix, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec}) b->release();
     }
 };
 
@@ -258,7 +258,7 @@ constexpr uint64_t kMaxVoxels = 1ull << 37;  // 16 GiB of bitmask
 
 // The shared front half of buildVoxelGrid for grids and the octree: records, unit counts, unit bases.
 vx_status run_setup(const vx_mesh* m, const vx::GridParams& g, int sat, uint64_t tb, uint32_t ntri, uint32_t zlo, uint32_t zhi, DevBuf& recs,
-                    DevBuf& units, DevBuf& ubase, DevBuf& scantmp, Small* ds, hipStream_t s, uint64_t* total_units)
+                    DevBuf& units, DevBuf& ubase, DevBuf& btri, DevBuf& scantmp, Small* ds, hipStream_t s, uint64_t* total_units)
 {
     VX_HIP(recs.ensure((size_t)ntri * sizeof(vx::TriRec) + 64));
     VX_HIP(units.ensure(((size_t)ntri + 1) * 4));
@@ -271,6 +271,10 @@ vx_status run_setup(const vx_mesh* m, const vx::GridParams& g, int sat, uint64_t
     VX_HIP(hipStreamSynchronize(s));
     if (tot >= 0xFFFFFFFFull) return fail(VX_ERR_CAPACITY, "more than 2^32 candidate row segments: shard the mesh or the grid");
     *total_units = tot;
+    if (tot) {
+        VX_HIP(btri.ensure((size_t)(tot / 256 + 2) * 4));
+        vx::launch_unit_blocks(ubase.as<uint32_t>(), ntri, btri.as<uint32_t>(), s);
+    }
     return VX_OK;
 }
 
@@ -500,15 +504,15 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
     const uint32_t zhi = (uint32_t)zh;
 
     uint64_t U = 0;
-    VX_TRY(run_setup(mesh, g->g, o.sat_variant, tb, ntri, zlo, zhi, g->recs, g->units, g->ubase, g->scantmp, ds, s, &U));
+    VX_TRY(run_setup(mesh, g->g, o.sat_variant, tb, ntri, zlo, zhi, g->recs, g->units, g->ubase, g->btri, g->scantmp, ds, s, &U));
     if (U == 0) return VX_OK;
     uint32_t* umask = nullptr;
     if (g->kind == VX_GRID_VEC) {
         VX_HIP(g->umask.ensure((size_t)(U + 1) * 4));
         umask = g->umask.as<uint32_t>();
     }
-    vx::launch_voxelize(g->recs.as<vx::TriRec>(), g->ubase.as<uint32_t>(), ntri, g->g, o.sat_variant, zlo, g->words.as<uint32_t>(), wb, we, umask,
-                        &ds->set_calls, s);
+    vx::launch_voxelize(g->recs.as<vx::TriRec>(), g->ubase.as<uint32_t>(), g->btri.as<uint32_t>(), ntri, g->g, o.sat_variant,
+                        g->words.as<uint32_t>(), wb, we, umask, &ds->set_calls, s);
     g->counts_valid = false;
     if (g->kind == VX_GRID_VEC) {
         // VoxelGridVec::setVoxel appends one Aabb per call (voxelgridVecEncoding.cpp:19-39): ordered emission
@@ -520,8 +524,8 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
         VX_HIP(hipStreamSynchronize(s));
         if (hits >= 0xFFFFFFFFull) return fail(VX_ERR_CAPACITY, "more than 2^32 voxel hits");
         VX_HIP(g->vec.ensure((size_t)(hits + 1) * sizeof(vx_aabb)));
-        vx::launch_emit_units(g->recs.as<vx::TriRec>(), g->ubase.as<uint32_t>(), ntri, g->g, zlo, umask, g->hbase.as<uint32_t>(),
-                              g->vec.as<vx_aabb>(), nullptr, s);
+        vx::launch_emit_units(g->recs.as<vx::TriRec>(), g->ubase.as<uint32_t>(), g->btri.as<uint32_t>(), ntri, g->g, umask,
+                              g->hbase.as<uint32_t>(), g->vec.as<vx_aabb>(), nullptr, s);
         g->vec_count = hits;
     }
     VX_HIP(hipGetLastError());
@@ -853,9 +857,9 @@ vx_status vx_octree_build(const vx_mesh* mesh_c, float vs, uint64_t max_items, v
     o->vs = vs;
     o->max_items = max_items;
     o->items.dev = o->device;
-    DevBuf small, recs, units, ubase, scantmp, umask, hbase, unsorted, sorttmp;
-    for (DevBuf* b : {&small, &recs, &units, &ubase, &scantmp, &umask, &hbase, &unsorted, &sorttmp}) b->dev = o->device;
-    auto cleanup = [&]() { for (DevBuf* b : {&small, &recs, &units, &ubase, &scantmp, &umask, &hbase, &unsorted, &sorttmp}) b->release(); };
+    DevBuf small, recs, units, ubase, btri, scantmp, umask, hbase, unsorted, sorttmp;
+    for (DevBuf* b : {&small, &recs, &units, &ubase, &btri, &scantmp, &umask, &hbase, &unsorted, &sorttmp}) b->dev = o->device;
+    auto cleanup = [&]() { for (DevBuf* b : {&small, &recs, &units, &ubase, &btri, &scantmp, &umask, &hbase, &unsorted, &sorttmp}) b->release(); };
     auto bail = [&](vx_status st) { cleanup(); o->items.release(); delete o; return st; };
 #define OCT_HIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return bail(fail(VX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__))); } while (0)
 #define OCT_TRY(expr) do { vx_status s__ = (expr); if (s__ != VX_OK) return bail(s__); } while (0)
@@ -876,14 +880,14 @@ vx_status vx_octree_build(const vx_mesh* mesh_c, float vs, uint64_t max_items, v
     vx::GridParams g;
     fill_params(g, ex.mn, vs, ex.dim);
     uint64_t U = 0;
-    OCT_TRY(run_setup(mesh, g, /*sat a7: octTree.hpp:762*/ 0, 0, ntri, 0, (uint32_t)ex.dim[2], recs, units, ubase, scantmp, ds, s, &U));
+    OCT_TRY(run_setup(mesh, g, /*sat a7: octTree.hpp:762*/ 0, 0, ntri, 0, (uint32_t)ex.dim[2], recs, units, ubase, btri, scantmp, ds, s, &U));
     unsigned long long hits = 0;
     if (U) {
         OCT_HIP(umask.ensure((size_t)(U + 1) * 4));
         OCT_HIP(hbase.ensure((size_t)(U + 2) * 4));
         OCT_HIP(scantmp.ensure(vx::scan_tmp_bytes(U)));
         OCT_HIP(hipMemsetAsync(&ds->set_calls, 0, 8, s));
-        vx::launch_voxelize(recs.as<vx::TriRec>(), ubase.as<uint32_t>(), ntri, g, 0, 0, nullptr, 0, 0, umask.as<uint32_t>(), &ds->set_calls, s);
+        vx::launch_voxelize(recs.as<vx::TriRec>(), ubase.as<uint32_t>(), btri.as<uint32_t>(), ntri, g, 0, nullptr, 0, 0, umask.as<uint32_t>(), &ds->set_calls, s);
         vx::launch_scan_u32(umask.as<uint32_t>(), hbase.as<uint32_t>(), U, true, scantmp.p, &ds->total_b, s);
         OCT_HIP(hipMemcpyAsync(&hits, &ds->total_b, 8, hipMemcpyDeviceToHost, s));
         OCT_HIP(hipStreamSynchronize(s));
@@ -894,8 +898,8 @@ vx_status vx_octree_build(const vx_mesh* mesh_c, float vs, uint64_t max_items, v
     if (hits) {
         OCT_HIP(unsorted.ensure((size_t)hits * 8));
         OCT_HIP(o->items.ensure((size_t)hits * 8));
-        vx::launch_emit_units(recs.as<vx::TriRec>(), ubase.as<uint32_t>(), ntri, g, 0, umask.as<uint32_t>(), hbase.as<uint32_t>(), nullptr,
-                              unsorted.as<uint64_t>(), s);
+        vx::launch_emit_units(recs.as<vx::TriRec>(), ubase.as<uint32_t>(), btri.as<uint32_t>(), ntri, g, umask.as<uint32_t>(), hbase.as<uint32_t>(),
+                              nullptr, unsorted.as<uint64_t>(), s);
         const size_t tb = vx::sort_tmp_bytes(hits);
         OCT_HIP(sorttmp.ensure(tb));
         vx::launch_sort_u64(unsorted.as<uint64_t>(), o->items.as<uint64_t>(), hits, (int)(3 * o->bits ? 3 * o->bits : 1), sorttmp.p, tb, s);

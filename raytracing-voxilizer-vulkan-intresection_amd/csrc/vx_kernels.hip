@@ -91,12 +91,22 @@ __global__ __launch_bounds__(256) void k_bbox(const float* __restrict__ verts, u
             mx[a] = o2 > mx[a] ? o2 : mx[a];
         }
     }
+    // one set of atomics per workgroup (every wave hitting the same six addresses serialises: 147 us -> a few us)
+    __shared__ unsigned long long red[4][6];
+    const int wv = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            atomicMin(&keys[a], mn[a]);
-            atomicMax(&keys[3 + a], mx[a]);
+        for (int a = 0; a < 3; ++a) { red[wv][a] = mn[a]; red[wv][3 + a] = mx[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int a = threadIdx.x;
+        unsigned long long v = red[0][a];
+        for (int w = 1; w < 4; ++w) {
+            const unsigned long long o = red[w][a];
+            v = a < 3 ? (o < v ? o : v) : (o > v ? o : v);
         }
+        if (a < 3) atomicMin(&keys[a], v); else atomicMax(&keys[a], v);
     }
 }
 
@@ -114,7 +124,7 @@ void launch_bbox(const float* verts, uint64_t nverts, unsigned long long* keys6,
 {
     static const unsigned long long init[6] = {~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull};
     hipMemcpyAsync(keys6, init, sizeof(init), hipMemcpyHostToDevice, s);
-    if (nverts) VX_KL(k_bbox, dim3(grid_for(nverts, 256, kMaxBlocks)), dim3(256), 0, s, verts, nverts, keys6);
+    if (nverts) VX_KL(k_bbox, dim3(grid_for(nverts, 256 * 4, 512)), dim3(256), 0, s, verts, nverts, keys6);
     VX_KL(k_bbox_finish, dim3(1), dim3(64), 0, s, verts, nverts, keys6, out6);
 }
 
@@ -344,22 +354,94 @@ __device__ __forceinline__ TriRec load_rec(const TriRec* __restrict__ recs, uint
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Unit -> triangle lookup without a per-lane global binary search (K2 was latency-bound on it: 61 % of wave cycles in
+// s_waitcnt).  k_unit_blocks records, for every 256-unit block, the triangle that owns the block's first unit; a workgroup
+// then stages the unit bases and the 48-byte records of the (few) triangles its 256 units belong to in LDS and every lane
+// searches there.  Blocks that span too many triangles (long runs of zero-unit triangles) fall back to the global search.
+// ------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kStageTris = 192;
+
+__global__ __launch_bounds__(256) void k_unit_blocks(const uint32_t* __restrict__ unit_base, uint32_t ntri, uint32_t* __restrict__ block_tri)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= ntri) return;
+    const uint32_t b0 = unit_base[t], b1 = unit_base[t + 1];
+    if (b1 <= b0) return;
+    const uint32_t k0 = (b0 + 255u) >> 8, k1 = (b1 - 1u) >> 8;
+    for (uint32_t k = k0; k <= k1 && k >= k0; ++k) block_tri[k] = t;
+}
+
+void launch_unit_blocks(const uint32_t* unit_base, uint32_t ntri, uint32_t* block_tri, hipStream_t s)
+{
+    if (!ntri) return;
+    VX_KL(k_unit_blocks, dim3((ntri + 255) / 256), dim3(256), 0, s, unit_base, ntri, block_tri);
+}
+
+struct UnitStage {
+    uint32_t base[kStageTris + 4];
+    float4 rec[kStageTris * 3];
+};
+
+// Calls f(u, triangle, record, u - unit_base[triangle]) for every work unit, one unit per lane, 256 per workgroup pass.
+template <class F>
+__device__ __forceinline__ void for_each_unit(const TriRec* __restrict__ recs, const uint32_t* __restrict__ unit_base,
+                                              const uint32_t* __restrict__ block_tri, uint32_t ntri, UnitStage& S, F&& f)
+{
+    const uint32_t U = unit_base[ntri];
+    const uint32_t nUB = (U + 255u) >> 8;
+    for (uint32_t ub = blockIdx.x; ub < nUB; ub += gridDim.x) {
+        const uint32_t u = (ub << 8) + threadIdx.x;
+        uint32_t t_lo = 0, n = 0xFFFFFFFFu;
+        if (block_tri) {
+            t_lo = block_tri[ub];
+            const uint32_t t_hi = (ub + 1 < nUB) ? block_tri[ub + 1] : ntri - 1;
+            n = t_hi - t_lo + 1;
+        }
+        const bool staged = n <= kStageTris;  // workgroup-uniform
+        if (staged) {
+            for (uint32_t i = threadIdx.x; i <= n; i += 256u) S.base[i] = unit_base[t_lo + i];
+            const float4* src = reinterpret_cast<const float4*>(recs + t_lo);
+            for (uint32_t i = threadIdx.x; i < n * 3u; i += 256u) S.rec[i] = src[i];
+            __syncthreads();
+        }
+        if (u < U) {
+            if (staged) {
+                uint32_t lo = 0, hi = n;  // S.base[lo] <= u < S.base[hi]
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (S.base[mid] <= u) lo = mid; else hi = mid;
+                }
+                const float4 a = S.rec[lo * 3], b = S.rec[lo * 3 + 1], c = S.rec[lo * 3 + 2];
+                TriRec r;
+                r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+                r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+                r.v[8] = c.x;
+                r.xr = __float_as_uint(c.y); r.yr = __float_as_uint(c.z); r.zr = __float_as_uint(c.w);
+                f(u, t_lo + lo, r, u - S.base[lo]);
+            } else {
+                const uint32_t t = find_tri(unit_base, ntri, u);
+                const TriRec r = load_rec(recs, t);
+                f(u, t, r, u - unit_base[t]);
+            }
+        }
+        if (staged) __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // K2  voxelize.  One lane per work unit.  The lane sweeps its <=32 voxels along x; everything of the SAT that does
 // not depend on x (two box axes, the three e x X axes, n.x) is evaluated once per row and can reject the whole row.
 // Hit bits are assembled in a register and leave the lane as at most two atomicOr (one when X % 32 == 0).
 // ------------------------------------------------------------------------------------------------------------
 template <bool EPS, bool STORE_MASK>
-__global__ __launch_bounds__(256) void k_voxelize(const TriRec* __restrict__ recs, const uint32_t* __restrict__ unit_base, uint32_t ntri,
-                                                  GridParams g, uint32_t* __restrict__ words, uint64_t wb, uint64_t we,
-                                                  uint32_t* __restrict__ unit_mask, unsigned long long* set_calls)
+__global__ __launch_bounds__(256) void k_voxelize(const TriRec* __restrict__ recs, const uint32_t* __restrict__ unit_base,
+                                                  const uint32_t* __restrict__ block_tri, uint32_t ntri, GridParams g, uint32_t* __restrict__ words,
+                                                  uint64_t wb, uint64_t we, uint32_t* __restrict__ unit_mask, unsigned long long* set_calls)
 {
-    const uint32_t U = unit_base[ntri];
+    __shared__ UnitStage stage;
     unsigned hits = 0;
-    for (uint64_t u64 = (uint64_t)blockIdx.x * 256u + threadIdx.x; u64 < U; u64 += (uint64_t)gridDim.x * 256u) {
-        const uint32_t u = (uint32_t)u64;
-        const uint32_t t = find_tri(unit_base, ntri, u);
-        const TriRec r = load_rec(recs, t);
-        const Unit w = decode_unit(r, t, u - unit_base[t]);
+    for_each_unit(recs, unit_base, block_tri, ntri, stage, [&](uint32_t u, uint32_t t, const TriRec& r, uint32_t rel) {
+        const Unit w = decode_unit(r, t, rel);
         const float cy = cell_centre(g.org[1], g.vs, w.y), cz = cell_centre(g.org[2], g.vs, w.z);
         const SatRow row = sat_row_setup<EPS>(r.v, cy, cz, g.half);
         uint32_t mask = 0;
@@ -379,22 +461,22 @@ __global__ __launch_bounds__(256) void k_voxelize(const TriRec* __restrict__ rec
             if (lo && wi >= wb && wi < we) { atomicOr(&words[wi], lo); hits += __popc(lo); }        // voxelgridBool.cpp:66
             if (hi && wi + 1 >= wb && wi + 1 < we) { atomicOr(&words[wi + 1], hi); hits += __popc(hi); }
         }
-    }
+    });
     hits = wave_sum_u32(hits);
     if ((threadIdx.x & 63) == 0 && hits) atomicAdd(set_calls, (unsigned long long)hits);
 }
 
-void launch_voxelize(const TriRec* recs, const uint32_t* unit_base, uint32_t ntri, const GridParams& g, int sat_variant, uint32_t /*zlo*/,
+void launch_voxelize(const TriRec* recs, const uint32_t* unit_base, const uint32_t* block_tri, uint32_t ntri, const GridParams& g, int sat_variant,
                      uint32_t* words, uint64_t wb, uint64_t we, uint32_t* unit_mask, unsigned long long* set_calls, hipStream_t s)
 {
     if (!ntri) return;
     const dim3 grid(kMaxBlocks), block(256);
     if (sat_variant == 0) {
-        if (unit_mask) VX_KL((k_voxelize<true, true>), grid, block, 0, s, recs, unit_base, ntri, g, words, wb, we, unit_mask, set_calls);
-        else VX_KL((k_voxelize<true, false>), grid, block, 0, s, recs, unit_base, ntri, g, words, wb, we, unit_mask, set_calls);
+        if (unit_mask) VX_KL((k_voxelize<true, true>), grid, block, 0, s, recs, unit_base, block_tri, ntri, g, words, wb, we, unit_mask, set_calls);
+        else VX_KL((k_voxelize<true, false>), grid, block, 0, s, recs, unit_base, block_tri, ntri, g, words, wb, we, unit_mask, set_calls);
     } else {
-        if (unit_mask) VX_KL((k_voxelize<false, true>), grid, block, 0, s, recs, unit_base, ntri, g, words, wb, we, unit_mask, set_calls);
-        else VX_KL((k_voxelize<false, false>), grid, block, 0, s, recs, unit_base, ntri, g, words, wb, we, unit_mask, set_calls);
+        if (unit_mask) VX_KL((k_voxelize<false, true>), grid, block, 0, s, recs, unit_base, block_tri, ntri, g, words, wb, we, unit_mask, set_calls);
+        else VX_KL((k_voxelize<false, false>), grid, block, 0, s, recs, unit_base, block_tri, ntri, g, words, wb, we, unit_mask, set_calls);
     }
 }
 
@@ -403,19 +485,16 @@ void launch_voxelize(const TriRec* recs, const uint32_t* unit_base, uint32_t ntr
 // of the reference's loop nest (VoxelBuilder.hpp:186-195), so hit_base (exclusive scan of popc(unit_mask)) is the
 // position of a unit's first hit in VoxelGridVec::m_voxel / in the octree's pre-sort item list.
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_emit_units(const TriRec* __restrict__ recs, const uint32_t* __restrict__ unit_base, uint32_t ntri,
-                                                    GridParams g, const uint32_t* __restrict__ unit_mask,
-                                                    const uint32_t* __restrict__ hit_base, vx_aabb* __restrict__ aabbs,
-                                                    uint64_t* __restrict__ morton)
+__global__ __launch_bounds__(256) void k_emit_units(const TriRec* __restrict__ recs, const uint32_t* __restrict__ unit_base,
+                                                    const uint32_t* __restrict__ block_tri, uint32_t ntri, GridParams g,
+                                                    const uint32_t* __restrict__ unit_mask, const uint32_t* __restrict__ hit_base,
+                                                    vx_aabb* __restrict__ aabbs, uint64_t* __restrict__ morton)
 {
-    const uint32_t U = unit_base[ntri];
-    for (uint64_t u64 = (uint64_t)blockIdx.x * 256u + threadIdx.x; u64 < U; u64 += (uint64_t)gridDim.x * 256u) {
-        const uint32_t u = (uint32_t)u64;
+    __shared__ UnitStage stage;
+    for_each_unit(recs, unit_base, block_tri, ntri, stage, [&](uint32_t u, uint32_t t, const TriRec& r, uint32_t rel) {
         uint32_t mask = unit_mask[u];
-        if (!mask) continue;
-        const uint32_t t = find_tri(unit_base, ntri, u);
-        const TriRec r = load_rec(recs, t);
-        const Unit w = decode_unit(r, t, u - unit_base[t]);
+        if (!mask) return;
+        const Unit w = decode_unit(r, t, rel);
         uint64_t off = hit_base[u];
         while (mask) {
             const uint32_t b = __ffs(mask) - 1;
@@ -432,14 +511,14 @@ __global__ __launch_bounds__(256) void k_emit_units(const TriRec* __restrict__ r
             if (morton) morton[off] = morton3d(x, w.y, w.z);  // octTree.hpp:765
             ++off;
         }
-    }
+    });
 }
 
-void launch_emit_units(const TriRec* recs, const uint32_t* unit_base, uint32_t ntri, const GridParams& g, uint32_t /*zlo*/,
+void launch_emit_units(const TriRec* recs, const uint32_t* unit_base, const uint32_t* block_tri, uint32_t ntri, const GridParams& g,
                        const uint32_t* unit_mask, const uint32_t* hit_base, vx_aabb* aabbs, uint64_t* morton, hipStream_t s)
 {
     if (!ntri) return;
-    VX_KL(k_emit_units, dim3(kMaxBlocks), dim3(256), 0, s, recs, unit_base, ntri, g, unit_mask, hit_base, aabbs, morton);
+    VX_KL(k_emit_units, dim3(kMaxBlocks), dim3(256), 0, s, recs, unit_base, block_tri, ntri, g, unit_mask, hit_base, aabbs, morton);
 }
 
 // ------------------------------------------------------------------------------------------------------------
