@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--rays", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-ray-sample", type=int, default=1500)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; the driver's multi-GPU runs) or gloo (rehearsal)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses device 0")
     return ap.parse_args()
 
 
@@ -66,13 +68,18 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
+    if a.single_device:
+        local = 0
     torch.cuda.set_device(local)
     voxhip.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(a.dist_backend, rank=rank, world_size=world)
     dev = torch.device("cuda", local)
 
     # ---- synthetic inputs, resident in HBM before anything is timed
@@ -149,7 +156,7 @@ def main():
     kern = voxhip.profile_read()
     stage_ms /= a.steps
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev if a.dist_backend == "nccl" else "cpu")
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())

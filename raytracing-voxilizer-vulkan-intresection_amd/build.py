@@ -15,7 +15,8 @@ LIB = os.path.join(HERE, "libvoxhip.so")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+EXTRA = os.environ.get("VOXHIP_EXTRA_FLAGS", "").split()
+FLAGS = EXTRA + ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
          "--offload-arch=" + ARCH]
 
 SOURCES = ["vx_kernels.hip", "vx_trace.hip", "vx_sort.hip", "vx_api.cpp", "vx_obj.cpp", "vx_prof.cpp"]

@@ -33,6 +33,8 @@
 // No MFMA: this is traversal, not a contraction.  Algorithmic HBM traffic is the ray stream (24 B in, 4-8 B out per ray).
 #include "vx_internal.h"
 
+#include <cstdlib>
+
 #pragma clang fp contract(off)
 
 namespace vx {
@@ -107,9 +109,7 @@ struct Lane {
     float t_in;                                // entry time of the current cell
     int lvl;
     bool skip_visit;
-    // level-0 slice cache
-    uint32_t ckey;
-    unsigned long long cbits;
+    float tolp;                                // position tolerance of this ray
 };
 
 // Axis selection BY VALUE.  `c ? R.x : R.y` on two struct members is an lvalue conditional: clang selects the ADDRESS and
@@ -189,8 +189,7 @@ __device__ __forceinline__ bool setup_ray(Lane& R, const GridParams& g, const Tr
     R.best_idx = ~0ull;
     R.lvl = 2;
     R.skip_visit = false;
-    R.ckey = 0xFFFFFFFFu;
-    R.cbits = 0ull;
+    R.tolp = tolp;
     R.px = R.py = R.pz = 0;
     if (miss || !(tn <= tf) || !g.nvox) return false;
     // one virtual cell of halo around the top level: a ray sliding along the outside of a boundary face within tolerance
@@ -199,11 +198,102 @@ __device__ __forceinline__ bool setup_ray(Lane& R, const GridParams& g, const Tr
     return true;
 }
 
-// One traversal step of the lane's ray at its current level: look at the current cell (and near-tie neighbours), then
-// descend, advance or pop.  Returns false when the ray is finished.
+// Level 0: all cells of one 8x8x8 brick the (tolerance-dilated) ray can touch, bit-parallel.
+// The brick is walked as z slices (one uint64 of occupancy each) and, inside a slice, as rows of 8 cells (one byte): for a
+// row the ray's x range is turned into a bit mask and ANDed with the occupancy byte, and only the surviving bits go through
+// the exact rint formula.  Every range is dilated by the position tolerance, so the tested set is a superset of the cells
+// the reference's float boxes could report; the slab formula is the arbiter.  A ray skimming along an occupied wall for a
+// whole brick costs a few row tests here instead of ~15 generic DDA steps (the tail of the step histogram: 1203 steps).
+__device__ __forceinline__ void brick_test(Lane& R, const GridParams& g, const TraceMips& M, float inv_vs, float tolp, int bx, int by, int bz, float tmin,
+                                           float tmax)
+{
+    const float vs = g.vs;
+    const int fx = bx * 8, fy = by * 8, fz = bz * 8;
+    const float lox = g.org[0] + (float)fx * vs, loy = g.org[1] + (float)fy * vs, loz = g.org[2] + (float)fz * vs;
+    const float hix = g.org[0] + (float)(fx + 8) * vs, hiy = g.org[1] + (float)(fy + 8) * vs, hiz = g.org[2] + (float)(fz + 8) * vs;
+    const float tauS = R.taux + R.tauy + R.tauz;
+    float ta = R.tn, tb = fminf(R.tf, R.best + tauS);
+    // the ray inside the dilated brick
+#define VX_CLIPB(o, d, inv, lo, hi)                                                         \
+    if ((d) == 0.0f) { if ((o) < (lo)-tolp || (o) > (hi) + tolp) return; }                   \
+    else {                                                                                   \
+        const float t1 = (((lo)-tolp) - (o)) * (inv), t2 = (((hi) + tolp) - (o)) * (inv);    \
+        ta = fmaxf(ta, fminf(t1, t2));                                                       \
+        tb = fminf(tb, fmaxf(t1, t2));                                                       \
+    }
+    VX_CLIPB(R.ox, R.dx, R.ix, lox, hix)
+    VX_CLIPB(R.oy, R.dy, R.iy, loy, hiy)
+    VX_CLIPB(R.oz, R.dz, R.iz, loz, hiz)
+#undef VX_CLIPB
+    if (!(ta <= tb)) return;
+    const float tol2 = 2.0f * tolp;  // positions derived from a time carry the time's error as well
+    const float za = R.oz + ta * R.dz, zb = R.oz + tb * R.dz;
+    int s0 = (int)floorf((fminf(za, zb) - tol2 - loz) * inv_vs), s1 = (int)floorf((fmaxf(za, zb) + tol2 - loz) * inv_vs);
+    s0 = s0 < 0 ? 0 : s0;
+    s1 = s1 > 7 ? 7 : s1;
+    const uint32_t bidx = (uint32_t)bx + M.d1[0] * ((uint32_t)by + M.d1[1] * (uint32_t)bz);
+    const unsigned long long* bp = M.bricks + (size_t)bidx * 8u;
+    const float o3[3] = {R.ox, R.oy, R.oz}, inv3[3] = {R.ix, R.iy, R.iz};
+    const bool zfwd = R.dz >= 0.0f;
+    for (int k = 0; k <= s1 - s0; ++k) {
+        const int s = zfwd ? s0 + k : s1 - k;
+        float tsa = ta, tsb = tb;
+        if (R.dz != 0.0f) {
+            const float pl = g.org[2] + (float)(fz + s) * vs, ph = g.org[2] + (float)(fz + s + 1) * vs;
+            const float t1 = ((pl - tolp) - R.oz) * R.iz, t2 = ((ph + tolp) - R.oz) * R.iz;
+            tsa = fmaxf(tsa, fminf(t1, t2));
+            tsb = fminf(tsb, fmaxf(t1, t2));
+        }
+        if (!(tsa <= tsb)) continue;
+        const unsigned long long bits = bp[s];
+        if (bits) {
+            const float ya = R.oy + tsa * R.dy, yb = R.oy + tsb * R.dy;
+            int r0 = (int)floorf((fminf(ya, yb) - tol2 - loy) * inv_vs), r1 = (int)floorf((fmaxf(ya, yb) + tol2 - loy) * inv_vs);
+            r0 = r0 < 0 ? 0 : r0;
+            r1 = r1 > 7 ? 7 : r1;
+            for (int r = r0; r <= r1; ++r) {
+                const uint32_t rowbits = (uint32_t)(bits >> (8 * r)) & 0xFFu;
+                if (!rowbits) continue;
+                float tra = tsa, trb = tsb;
+                if (R.dy != 0.0f) {
+                    const float pl = g.org[1] + (float)(fy + r) * vs, ph = g.org[1] + (float)(fy + r + 1) * vs;
+                    const float t1 = ((pl - tolp) - R.oy) * R.iy, t2 = ((ph + tolp) - R.oy) * R.iy;
+                    tra = fmaxf(tra, fminf(t1, t2));
+                    trb = fminf(trb, fmaxf(t1, t2));
+                }
+                if (!(tra <= trb)) continue;
+                const float xa = R.ox + tra * R.dx, xb = R.ox + trb * R.dx;
+                int c0 = (int)floorf((fminf(xa, xb) - tol2 - lox) * inv_vs), c1 = (int)floorf((fmaxf(xa, xb) + tol2 - lox) * inv_vs);
+                c0 = c0 < 0 ? 0 : c0;
+                c1 = c1 > 7 ? 7 : c1;
+                if (c0 > c1) continue;
+                uint32_t cand = rowbits & ((2u << c1) - (1u << c0));
+                while (cand) {
+                    const int b = __ffs(cand) - 1;
+                    cand &= cand - 1;
+                    const uint32_t x = (uint32_t)(fx + b), y = (uint32_t)(fy + r), z = (uint32_t)(fz + s);
+                    float bb[6];
+                    cell_aabb(g, x, y, z, bb);
+                    const float t = hit_aabb(bb, o3, inv3);                       // rint:46-56
+                    const uint64_t i = (uint64_t)x + (uint64_t)g.dim[0] * ((uint64_t)y + (uint64_t)g.dim[1] * (uint64_t)z);
+                    if (t > 0.0f && t >= tmin && t <= tmax &&                     // rint:69, rgen:50-51
+                        (t < R.best || (t == R.best && i < R.best_idx))) {
+                        R.best = t;
+                        R.best_idx = i;
+                    }
+                }
+            }
+        }
+        // cells of later slices are entered no earlier than this slice is left
+        if (R.best + 2.0f * tauS < tsb) return;
+    }
+}
+
+// One traversal step of the lane's ray at its current level (2: 64^3 blocks, 1: bricks): look at the current cell and its
+// near-tie neighbours, then descend, advance or pop.  Returns false when the ray is finished.
 template <bool LDS_M1>
-__device__ __forceinline__ bool step_ray(Lane& R, const GridParams& g, const TraceMips& M, const uint32_t* __restrict__ m1_lds, float inv_vs, float tmin,
-                                         float tmax)
+__device__ __forceinline__ bool step_ray(Lane& R, const GridParams& g, const TraceMips& M, const uint32_t* __restrict__ m1_lds, float inv_vs, float tolp,
+                                         float tmin, float tmax)
 {
     const int lvl = R.lvl;
     const bool ex = (R.tMx <= R.tMy) && (R.tMx <= R.tMz);
@@ -214,29 +304,11 @@ __device__ __forceinline__ bool step_ray(Lane& R, const GridParams& g, const Tra
     if (!R.skip_visit) {
         bool occ = false;
         auto look = [&](int nx, int ny, int nz) {
-            if (lvl == 0) {
-                if ((unsigned)nx >= g.dim[0] || (unsigned)ny >= g.dim[1] || (unsigned)nz >= g.dim[2]) return;
-                const uint32_t key = (((uint32_t)nx >> 3) + M.d1[0] * (((uint32_t)ny >> 3) + M.d1[1] * ((uint32_t)nz >> 3))) * 8u + ((uint32_t)nz & 7u);
-                if (key != R.ckey) {
-                    R.cbits = M.bricks[key];
-                    R.ckey = key;
-                }
-                if (!((R.cbits >> ((((uint32_t)ny & 7u) << 3) + ((uint32_t)nx & 7u))) & 1ull)) return;
-                float bb[6];
-                cell_aabb(g, (uint32_t)nx, (uint32_t)ny, (uint32_t)nz, bb);
-                const float o3[3] = {R.ox, R.oy, R.oz}, inv3[3] = {R.ix, R.iy, R.iz};
-                const float t = hit_aabb(bb, o3, inv3);                       // rint:46-56
-                const uint64_t i = (uint64_t)nx + (uint64_t)g.dim[0] * ((uint64_t)ny + (uint64_t)g.dim[1] * (uint64_t)nz);
-                if (t > 0.0f && t >= tmin && t <= tmax &&                     // rint:69, rgen:50-51
-                    (t < R.best || (t == R.best && i < R.best_idx))) {
-                    R.best = t;
-                    R.best_idx = i;
-                }
-            } else if (lvl == 1) {
+            if (lvl == 1) {
                 if ((unsigned)nx >= M.d1[0] || (unsigned)ny >= M.d1[1] || (unsigned)nz >= M.d1[2]) return;
                 const uint32_t i = (uint32_t)nx + M.d1[0] * ((uint32_t)ny + M.d1[1] * (uint32_t)nz);
                 const uint32_t w = LDS_M1 ? m1_lds[i >> 5] : M.w1[i >> 5];
-                occ |= ((w >> (i & 31u)) & 1u) != 0u;
+                if ((w >> (i & 31u)) & 1u) brick_test(R, g, M, inv_vs, tolp, nx, ny, nz, tmin, tmax);
             } else {
                 if ((unsigned)nx >= M.d2[0] || (unsigned)ny >= M.d2[1] || (unsigned)nz >= M.d2[2]) return;
                 const uint32_t i = (uint32_t)nx + M.d2[0] * ((uint32_t)ny + M.d2[1] * (uint32_t)nz);
@@ -277,12 +349,12 @@ __device__ __forceinline__ bool step_ray(Lane& R, const GridParams& g, const Tra
             }
         }
         if (occ) {
-            // descend into the NOMINAL cell's children, starting exactly at its entry time (a time slack would slide the
-            // start point along the ray's major axis; the start cell's rounding is covered by the child walk's probes)
+            // descend into the NOMINAL block's bricks, starting exactly at its entry time (a time slack would slide the
+            // start point along the ray's major axis; the start cell's rounding is covered by the brick walk's probes)
             R.px = R.cx; R.py = R.cy; R.pz = R.cz;
             const int lx = R.cx * 8, ly = R.cy * 8, lz = R.cz * 8;
-            enter_level(R, g, inv_vs, (lvl - 1) * 3, lx, ly, lz, lx + 8, ly + 8, lz + 8, fmaxf(R.t_in, R.tn));
-            R.lvl = lvl - 1;
+            enter_level(R, g, inv_vs, 3, lx, ly, lz, lx + 8, ly + 8, lz + 8, fmaxf(R.t_in, R.tn));
+            R.lvl = 1;
             return true;
         }
     }
@@ -311,16 +383,14 @@ __device__ __forceinline__ bool step_ray(Lane& R, const GridParams& g, const Tra
     R.tau_ent = tau_exit_adv;
     R.t_in = t_o;
     if (out) {
-        // left the parent cell: resume the parent level (its plane times are recomputed, not stored) and let it advance
-        // on the next step
+        // left the block: resume the block level (its plane times are recomputed, not stored) and let it advance on the
+        // next step
         if (lvl == 2) return false;
-        const int nl = lvl + 1;
         R.cx = R.px; R.cy = R.py; R.cz = R.pz;
-        R.px >>= 3; R.py >>= 3; R.pz >>= 3;  // parent of the parent (unused at the top level)
-        axis_planes(R.tMx, R.tPx, R.cx, R.ox, R.dx, R.ix, g.org[0], g.vs, nl * 3);
-        axis_planes(R.tMy, R.tPy, R.cy, R.oy, R.dy, R.iy, g.org[1], g.vs, nl * 3);
-        axis_planes(R.tMz, R.tPz, R.cz, R.oz, R.dz, R.iz, g.org[2], g.vs, nl * 3);
-        R.lvl = nl;
+        axis_planes(R.tMx, R.tPx, R.cx, R.ox, R.dx, R.ix, g.org[0], g.vs, 6);
+        axis_planes(R.tMy, R.tPy, R.cy, R.oy, R.dy, R.iy, g.org[1], g.vs, 6);
+        axis_planes(R.tMz, R.tPz, R.cz, R.oz, R.dz, R.iz, g.org[2], g.vs, 6);
+        R.lvl = 2;
         R.skip_visit = true;
     }
     return true;
@@ -334,15 +404,13 @@ template <bool PRIMARY, bool WANT_PRIM, bool LDS_M1>
 __global__ __launch_bounds__(256) void k_trace(GridParams g, TraceMips M, const uint32_t* __restrict__ word_prefix, const float* __restrict__ rays,
                                                Camera cam, uint64_t nrays, float tmin, float tmax, float* __restrict__ t_out,
                                                uint32_t* __restrict__ prim_out, vx_hit* __restrict__ hits, unsigned long long* nhits,
-                                               unsigned long long* next_ray, uint32_t m1_words)
+                                               unsigned long long* next_ray, uint32_t m1_words, int kStepsPerRound, int kRefillBelow)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t m1_lds[];
     if (LDS_M1) {
         for (uint32_t i = threadIdx.x; i < m1_words; i += 256u) m1_lds[i] = M.w1[i];
         __syncthreads();
     }
-    constexpr int kStepsPerRound = 8;   // traversal steps between two refill checks
-    constexpr int kRefillBelow = 44;    // refill when fewer than this many lanes are busy
     const int lane = threadIdx.x & 63;
     const float inv_vs = 1.0f / g.vs;
     Lane R;
@@ -403,7 +471,7 @@ __global__ __launch_bounds__(256) void k_trace(GridParams g, TraceMips M, const 
         if (busy) {
 #pragma unroll 1
             for (int k = 0; k < kStepsPerRound; ++k) {
-                if (!step_ray<LDS_M1>(R, g, M, m1_lds, inv_vs, tmin, tmax) || --steps_left <= 0) { finished = true; break; }
+                if (!step_ray<LDS_M1>(R, g, M, m1_lds, inv_vs, R.tolp, tmin, tmax) || --steps_left <= 0) { finished = true; break; }
             }
         }
         // ---- retire
@@ -419,6 +487,9 @@ __global__ __launch_bounds__(256) void k_trace(GridParams g, TraceMips M, const 
                 } else
                     best_prim = 0;
             }
+#ifdef VX_TRACE_DEBUG_STEPS
+            best_t = (float)((1 << 20) - steps_left);  // diagnostic build: report the step count instead of t
+#endif
             if (t_out) t_out[r] = best_t;
             if (WANT_PRIM && prim_out) prim_out[r] = best_prim;
             busy = false;
@@ -455,13 +526,16 @@ void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* wo
     const uint32_t m1_words = (uint32_t)((n1 + 31) / 32);
     const bool lds_m1 = (size_t)m1_words * 4 <= 40960;  // 4 workgroups x 40 KiB fit the CU's 160 KiB
     // persistent grid: 256 CUs x 4 resident 256-thread workgroups, fewer when there are not that many rays
+    static const int env_blocks = getenv("VOXHIP_TRACE_BLOCKS") ? atoi(getenv("VOXHIP_TRACE_BLOCKS")) : 1024;
+    static const int env_steps = getenv("VOXHIP_TRACE_STEPS") ? atoi(getenv("VOXHIP_TRACE_STEPS")) : 8;
+    static const int env_refill = getenv("VOXHIP_TRACE_REFILL") ? atoi(getenv("VOXHIP_TRACE_REFILL")) : 44;
     uint64_t nblk = (nrays + 255) / 256;
-    if (nblk > 1024) nblk = 1024;
+    if (nblk > (uint64_t)env_blocks) nblk = (uint64_t)env_blocks;
     const dim3 grid((unsigned)nblk), block(256);
     const bool want_prim = word_prefix != nullptr;
     const size_t shmem = lds_m1 ? (size_t)m1_words * 4 : 0;
 #define VX_LAUNCH(P, W, L) \
-    VX_KL((k_trace<P, W, L>), grid, block, shmem, s, g, mips, word_prefix, rays, c, nrays, tmin, tmax, t_out, prim_out, hits, nhits, next_ray, m1_words)
+    VX_KL((k_trace<P, W, L>), grid, block, shmem, s, g, mips, word_prefix, rays, c, nrays, tmin, tmax, t_out, prim_out, hits, nhits, next_ray, m1_words, env_steps, env_refill)
 #define VX_LAUNCH2(P, W) do { if (lds_m1) VX_LAUNCH(P, W, true); else VX_LAUNCH(P, W, false); } while (0)
     if (cam) { if (want_prim) VX_LAUNCH2(true, true); else VX_LAUNCH2(true, false); }
     else { if (want_prim) VX_LAUNCH2(false, true); else VX_LAUNCH2(false, false); }

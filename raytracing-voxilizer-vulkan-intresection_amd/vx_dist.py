@@ -19,9 +19,17 @@ def exchange_bitmask(mask, gathered, wb, we, chunk, dist):
     send = torch.zeros(chunk, dtype=mask.dtype, device=mask.device)
     if we > wb:
         send[: we - wb] = mask[wb:we]
-    dist.all_gather_into_tensor(gathered, send) if hasattr(dist, "all_gather_into_tensor") and gathered.is_cuda else \
+    if mask.is_cuda and dist.get_backend() == "nccl":
+        dist.all_gather_into_tensor(gathered, send)          # RCCL over xGMI: the production path
+        mask.copy_(gathered[:n])
+    elif mask.is_cuda:
+        # rehearsal on a box without RCCL peers (gloo): stage through host memory
+        hs, hg = send.cpu(), torch.empty(chunk * world, dtype=mask.dtype)
+        _gather_fallback(hg, hs, chunk, world, dist)
+        mask.copy_(hg[:n].to(mask.device))
+    else:
         _gather_fallback(gathered, send, chunk, world, dist)
-    mask.copy_(gathered[:n])
+        mask.copy_(gathered[:n])
     return mask
 
 
