@@ -169,18 +169,18 @@ struct vx_grid {
     float bbmin[3] = {0, 0, 0}, bbmax[3] = {0, 0, 0}, bbc[3] = {0, 0, 0};
     uint64_t triangles = 0;
     uint32_t cdim[3] = {0, 0, 0}, c2dim[3] = {0, 0, 0};
-    DevBuf words, cwords, c2words, bricks, wprefix, recs, units, ubase, btri, umask, hbase, scantmp, small, vec;
+    DevBuf words, cwords, c2words, bricks, bbounds, wprefix, recs, units, ubase, btri, umask, hbase, scantmp, small, vec;
     bool coarse_valid = false, prefix_valid = false, counts_valid = true;
     uint64_t occupied = 0, set_calls = 0, host_set_calls = 0;
     uint64_t vec_count = 0;
     void set_dev(int d)
     {
         device = d;
-        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &wprefix, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec}) b->dev = d;
+        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &bbounds, &wprefix, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec}) b->dev = d;
     }
     void release_all()
     {
-        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &wprefix, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec}) b->release();
+        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &bbounds, &wprefix, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec}) b->release();
     }
 };
 
@@ -311,6 +311,8 @@ vx_status ensure_coarse(vx_grid* g)
     vx::launch_build_coarse(g->cwords.as<uint32_t>(), g->cdim, g->c2dim, g->c2words.as<uint32_t>(), g->stream);
     VX_HIP(g->bricks.ensure((size_t)(nc * 8 + 8) * 8));
     vx::launch_build_bricks(g->words.as<uint32_t>(), g->g.dim, g->cdim, g->bricks.as<unsigned long long>(), g->stream);
+    VX_HIP(g->bbounds.ensure((size_t)(nc + 8) * 4));
+    vx::launch_brick_bounds(g->bricks.as<unsigned long long>(), nc, g->bbounds.as<uint32_t>(), g->stream);
     g->coarse_valid = true;
     return VX_OK;
 }
@@ -748,6 +750,7 @@ static vx_status trace_common(vx_grid* g, const float* dev_rays, const vx::Camer
     if (dev_prim || dev_hits) { VX_TRY(ensure_prefix(g)); prefix = g->wprefix.as<uint32_t>(); }
     vx::TraceMips mips;
     mips.bricks = g->bricks.as<unsigned long long>();
+    mips.bounds = g->bbounds.as<uint32_t>();
     mips.w0 = g->words.as<uint32_t>();
     mips.w1 = g->cwords.as<uint32_t>();
     mips.w2 = g->c2words.as<uint32_t>();

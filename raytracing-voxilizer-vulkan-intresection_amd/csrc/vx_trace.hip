@@ -89,6 +89,42 @@ void launch_build_bricks(const uint32_t* words, const uint32_t dim[3], const uin
     VX_KL(k_build_bricks, dim3((unsigned)nblk), dim3(256), 0, s, words, dim[0], dim[1], dim[2], bdim[0], bdim[1], bdim[2], bricks);
 }
 
+// Per brick: the bounding box of its occupied cells, 3 bits per bound (xmin | xmax<<3 | ymin<<6 | ymax<<9 | zmin<<12 |
+// zmax<<15).  Voxelized meshes are thin shells: a ray that crosses a wall's or a floor's brick without touching the
+// one-voxel layer is rejected by one box-vs-box test instead of a walk over the brick's slices and rows.
+__global__ __launch_bounds__(256) void k_brick_bounds(const unsigned long long* __restrict__ bricks, uint64_t nbricks, uint32_t* __restrict__ bounds)
+{
+    for (uint64_t b = (uint64_t)blockIdx.x * 256u + threadIdx.x; b < nbricks; b += (uint64_t)gridDim.x * 256u) {
+        unsigned long long any = 0;
+        uint32_t zmin = 7, zmax = 0;
+        for (uint32_t s = 0; s < 8u; ++s) {
+            const unsigned long long v = bricks[b * 8ull + s];
+            if (v) { zmin = s < zmin ? s : zmin; zmax = s; }
+            any |= v;
+        }
+        uint32_t out = 0;
+        if (any) {
+            uint32_t rows = 0, cols = 0;  // rows: which y have a bit; cols: which x have a bit
+            for (uint32_t y = 0; y < 8u; ++y) {
+                const uint32_t byte = (uint32_t)(any >> (8u * y)) & 0xFFu;
+                if (byte) rows |= 1u << y;
+                cols |= byte;
+            }
+            const uint32_t xmin = __ffs(cols) - 1, xmax = 31 - __clz(cols), ymin = __ffs(rows) - 1, ymax = 31 - __clz(rows);
+            out = xmin | (xmax << 3) | (ymin << 6) | (ymax << 9) | (zmin << 12) | (zmax << 15) | (1u << 18);
+        }
+        bounds[b] = out;
+    }
+}
+
+void launch_brick_bounds(const unsigned long long* bricks, uint64_t nbricks, uint32_t* bounds, hipStream_t s)
+{
+    if (!nbricks) return;
+    uint64_t nblk = (nbricks + 255) / 256;
+    if (nblk > 4096) nblk = 4096;
+    VX_KL(k_brick_bounds, dim3((unsigned)nblk), dim3(256), 0, s, bricks, nbricks, bounds);
+}
+
 namespace {
 
 // everything a lane carries for the ray it is currently tracing
@@ -108,8 +144,14 @@ struct Lane {
     float tPx, tPy, tPz;                       // time of the plane behind per axis
     float t_in;                                // entry time of the current cell
     int lvl;
-    bool skip_visit;
     float tolp;                                // position tolerance of this ray
+    float tau_term;                            // termination margin: 2 x the tolerance of the ray's major axis
+    // visit protocol of the current cell: cells still to look at (bit j = jx + 3*jy + 9*jz, 0 stay / 1 forward / 2 backward)
+    uint32_t todo;
+    bool fresh;                                // the current cell has not been expanded into `todo` yet
+    bool occ;                                  // level 2: the block or a probed neighbour holds something
+    bool pending;                              // level 1: an occupied brick waits for its brick test
+    int bx, by, bz;                            // that brick
 };
 
 // Axis selection BY VALUE.  `c ? R.x : R.y` on two struct members is an lvalue conditional: clang selects the ADDRESS and
@@ -188,8 +230,13 @@ __device__ __forceinline__ bool setup_ray(Lane& R, const GridParams& g, const Tr
     R.best = INFINITY;
     R.best_idx = ~0ull;
     R.lvl = 2;
-    R.skip_visit = false;
     R.tolp = tolp;
+    R.tau_term = 2.0f * tolp / fmaxf(fmaxf(fabsf(R.dx), fabsf(R.dy)), fabsf(R.dz));
+    R.todo = 0u;
+    R.fresh = true;
+    R.occ = false;
+    R.pending = false;
+    R.bx = R.by = R.bz = 0;
     R.px = R.py = R.pz = 0;
     if (miss || !(tn <= tf) || !g.nvox) return false;
     // one virtual cell of halo around the top level: a ray sliding along the outside of a boundary face within tolerance
@@ -227,11 +274,21 @@ __device__ __forceinline__ void brick_test(Lane& R, const GridParams& g, const T
 #undef VX_CLIPB
     if (!(ta <= tb)) return;
     const float tol2 = 2.0f * tolp;  // positions derived from a time carry the time's error as well
+    const uint32_t bidx = (uint32_t)bx + M.d1[0] * ((uint32_t)by + M.d1[1] * (uint32_t)bz);
+    // the (dilated) cell box of the ray segment inside the brick against the box of the brick's occupied cells
+    const uint32_t ob = M.bounds[bidx];
+    const int oxmin = ob & 7u, oxmax = (ob >> 3) & 7u, oymin = (ob >> 6) & 7u, oymax = (ob >> 9) & 7u, ozmin = (ob >> 12) & 7u, ozmax = (ob >> 15) & 7u;
+    const float xa0 = R.ox + ta * R.dx, xb0 = R.ox + tb * R.dx;
+    const int cb0 = (int)floorf((fminf(xa0, xb0) - tol2 - lox) * inv_vs), cb1 = (int)floorf((fmaxf(xa0, xb0) + tol2 - lox) * inv_vs);
+    if (cb1 < oxmin || cb0 > oxmax) return;
+    const float ya0 = R.oy + ta * R.dy, yb0 = R.oy + tb * R.dy;
+    const int rb0 = (int)floorf((fminf(ya0, yb0) - tol2 - loy) * inv_vs), rb1 = (int)floorf((fmaxf(ya0, yb0) + tol2 - loy) * inv_vs);
+    if (rb1 < oymin || rb0 > oymax) return;
     const float za = R.oz + ta * R.dz, zb = R.oz + tb * R.dz;
     int s0 = (int)floorf((fminf(za, zb) - tol2 - loz) * inv_vs), s1 = (int)floorf((fmaxf(za, zb) + tol2 - loz) * inv_vs);
-    s0 = s0 < 0 ? 0 : s0;
-    s1 = s1 > 7 ? 7 : s1;
-    const uint32_t bidx = (uint32_t)bx + M.d1[0] * ((uint32_t)by + M.d1[1] * (uint32_t)bz);
+    s0 = s0 < ozmin ? ozmin : s0;
+    s1 = s1 > ozmax ? ozmax : s1;
+    if (s0 > s1) return;
     const unsigned long long* bp = M.bricks + (size_t)bidx * 8u;
     const float o3[3] = {R.ox, R.oy, R.oz}, inv3[3] = {R.ix, R.iy, R.iz};
     const bool zfwd = R.dz >= 0.0f;
@@ -249,8 +306,8 @@ __device__ __forceinline__ void brick_test(Lane& R, const GridParams& g, const T
         if (bits) {
             const float ya = R.oy + tsa * R.dy, yb = R.oy + tsb * R.dy;
             int r0 = (int)floorf((fminf(ya, yb) - tol2 - loy) * inv_vs), r1 = (int)floorf((fmaxf(ya, yb) + tol2 - loy) * inv_vs);
-            r0 = r0 < 0 ? 0 : r0;
-            r1 = r1 > 7 ? 7 : r1;
+            r0 = r0 < oymin ? oymin : r0;
+            r1 = r1 > oymax ? oymax : r1;
             for (int r = r0; r <= r1; ++r) {
                 const uint32_t rowbits = (uint32_t)(bits >> (8 * r)) & 0xFFu;
                 if (!rowbits) continue;
@@ -284,16 +341,18 @@ __device__ __forceinline__ void brick_test(Lane& R, const GridParams& g, const T
                 }
             }
         }
-        // cells of later slices are entered no earlier than this slice is left
-        if (R.best + 2.0f * tauS < tsb) return;
+        // cells of later slices are entered (in z) no earlier than this slice's dilated exit minus the z tolerance
+        if (R.best + 2.0f * R.tauz + R.tau_term < tsb) return;
     }
 }
 
-// One traversal step of the lane's ray at its current level (2: 64^3 blocks, 1: bricks): look at the current cell and its
-// near-tie neighbours, then descend, advance or pop.  Returns false when the ray is finished.
+// One step of the upper-level walk (level 2: 64^3-cell blocks, level 1: bricks).  A step either looks at ONE cell of the
+// current visit list (the walk's cell, then its near-tie neighbours) or finishes the cell (descend / advance / pop).  At
+// level 1 an occupied cell is not processed here: it is posted as the lane's pending brick, and the caller runs the brick
+// test for all lanes of the wave together (phase separation keeps the wave's lanes in the same code).
+// Returns false when the ray is finished.
 template <bool LDS_M1>
-__device__ __forceinline__ bool step_ray(Lane& R, const GridParams& g, const TraceMips& M, const uint32_t* __restrict__ m1_lds, float inv_vs, float tolp,
-                                         float tmin, float tmax)
+__device__ __forceinline__ bool upper_step(Lane& R, const GridParams& g, const TraceMips& M, const uint32_t* __restrict__ m1_lds, float inv_vs)
 {
     const int lvl = R.lvl;
     const bool ex = (R.tMx <= R.tMy) && (R.tMx <= R.tMz);
@@ -301,22 +360,8 @@ __device__ __forceinline__ bool step_ray(Lane& R, const GridParams& g, const Tra
     const float t_o = sel3(ex, ey, R.tMx, R.tMy, R.tMz);
     const int sx = R.dx < 0.0f ? -1 : 1, sy = R.dy < 0.0f ? -1 : 1, sz = R.dz < 0.0f ? -1 : 1;
     const float tauS = R.taux + R.tauy + R.tauz;
-    if (!R.skip_visit) {
-        bool occ = false;
-        auto look = [&](int nx, int ny, int nz) {
-            if (lvl == 1) {
-                if ((unsigned)nx >= M.d1[0] || (unsigned)ny >= M.d1[1] || (unsigned)nz >= M.d1[2]) return;
-                const uint32_t i = (uint32_t)nx + M.d1[0] * ((uint32_t)ny + M.d1[1] * (uint32_t)nz);
-                const uint32_t w = LDS_M1 ? m1_lds[i >> 5] : M.w1[i >> 5];
-                if ((w >> (i & 31u)) & 1u) brick_test(R, g, M, inv_vs, tolp, nx, ny, nz, tmin, tmax);
-            } else {
-                if ((unsigned)nx >= M.d2[0] || (unsigned)ny >= M.d2[1] || (unsigned)nz >= M.d2[2]) return;
-                const uint32_t i = (uint32_t)nx + M.d2[0] * ((uint32_t)ny + M.d2[1] * (uint32_t)nz);
-                occ |= ((M.w2[i >> 5] >> (i & 31u)) & 1u) != 0u;
-            }
-        };
-        look(R.cx, R.cy, R.cz);
-        // forward near-ties (other axes' next planes), backward near-ties (planes just behind)
+    if (R.fresh) {
+        // forward near-ties (other axes' next planes), backward near-ties (planes just behind) -> per-axis offset sets
         const float tau_exit = sel3(ex, ey, R.taux, R.tauy, R.tauz);
         const bool start = R.emask == 0;
         const bool ez = !ex && !ey;
@@ -326,41 +371,55 @@ __device__ __forceinline__ bool step_ray(Lane& R, const GridParams& g, const Tra
         const bool bx = !(R.emask & 1) && (R.t_in - R.tPx <= R.taux + sel3(start, false, R.taux, 0.0f, R.tau_ent));
         const bool by = !(R.emask & 2) && (R.t_in - R.tPy <= R.tauy + sel3(start, false, R.tauy, 0.0f, R.tau_ent));
         const bool bz = !(R.emask & 4) && (R.t_in - R.tPz <= R.tauz + sel3(start, false, R.tauz, 0.0f, R.tau_ent));
-        if (fx | fy | fz | bx | by | bz) {
-            if ((fx & bx) | (fy & by) | (fz & bz)) {
-                // a cell crossed in less than the tolerance: both directions of an axis are in play (very rare)
-                for (int j = 1; j < 27; ++j) {
-                    const int jx = j % 3, jy = (j / 3) % 3, jz = j / 9;  // 0: stay, 1: forward, 2: backward
-                    const bool okx = jx == 0 || (jx == 1 ? fx : bx);
-                    const bool oky = jy == 0 || (jy == 1 ? fy : by);
-                    const bool okz = jz == 0 || (jz == 1 ? fz : bz);
-                    if (!(okx && oky && okz)) continue;
-                    look(R.cx + (jx == 0 ? 0 : (jx == 1 ? sx : -sx)), R.cy + (jy == 0 ? 0 : (jy == 1 ? sy : -sy)),
-                         R.cz + (jz == 0 ? 0 : (jz == 1 ? sz : -sz)));
-                }
-            } else {
-                // one direction per flagged axis: the non-empty subsets of the flagged axes
-                const int ax = fx ? sx : (bx ? -sx : 0), ay = fy ? sy : (by ? -sy : 0), az = fz ? sz : (bz ? -sz : 0);
-                const int fm = (ax != 0 ? 1 : 0) | (ay != 0 ? 2 : 0) | (az != 0 ? 4 : 0);
-                for (int m = 1; m < 8; ++m) {
-                    if (m & ~fm) continue;
-                    look(R.cx + ((m & 1) ? ax : 0), R.cy + ((m & 2) ? ay : 0), R.cz + ((m & 4) ? az : 0));
+        const uint32_t mx = 1u | (fx ? 2u : 0u) | (bx ? 4u : 0u);
+        const uint32_t my = 1u | (fy ? 1u << 3 : 0u) | (by ? 1u << 6 : 0u);
+        const uint32_t mz = 1u | (fz ? 1u << 9 : 0u) | (bz ? 1u << 18 : 0u);
+        R.todo = (mx * my) * mz;  // bit (jx + 3 jy + 9 jz) set iff every axis allows its offset; bit 0 = the cell itself
+        R.fresh = false;
+        R.occ = false;
+    }
+    if (R.todo) {
+        const int j = __ffs(R.todo) - 1;
+        R.todo &= R.todo - 1;
+        const int jx = j % 3, jy = (j / 3) % 3, jz = j / 9;
+        const int nx = R.cx + (jx == 0 ? 0 : (jx == 1 ? sx : -sx));
+        const int ny = R.cy + (jy == 0 ? 0 : (jy == 1 ? sy : -sy));
+        const int nz = R.cz + (jz == 0 ? 0 : (jz == 1 ? sz : -sz));
+        if (lvl == 1) {
+            if ((unsigned)nx < M.d1[0] && (unsigned)ny < M.d1[1] && (unsigned)nz < M.d1[2]) {
+                const uint32_t i = (uint32_t)nx + M.d1[0] * ((uint32_t)ny + M.d1[1] * (uint32_t)nz);
+                const uint32_t w = LDS_M1 ? m1_lds[i >> 5] : M.w1[i >> 5];
+                if ((w >> (i & 31u)) & 1u) {
+                    R.pending = true;
+                    R.bx = nx; R.by = ny; R.bz = nz;
+                    return true;
                 }
             }
+        } else {
+            if ((unsigned)nx < M.d2[0] && (unsigned)ny < M.d2[1] && (unsigned)nz < M.d2[2]) {
+                const uint32_t i = (uint32_t)nx + M.d2[0] * ((uint32_t)ny + M.d2[1] * (uint32_t)nz);
+                R.occ |= ((M.w2[i >> 5] >> (i & 31u)) & 1u) != 0u;
+            }
         }
-        if (occ) {
-            // descend into the NOMINAL block's bricks, starting exactly at its entry time (a time slack would slide the
-            // start point along the ray's major axis; the start cell's rounding is covered by the brick walk's probes)
-            R.px = R.cx; R.py = R.cy; R.pz = R.cz;
-            const int lx = R.cx * 8, ly = R.cy * 8, lz = R.cz * 8;
-            enter_level(R, g, inv_vs, 3, lx, ly, lz, lx + 8, ly + 8, lz + 8, fmaxf(R.t_in, R.tn));
-            R.lvl = 1;
-            return true;
-        }
+        if (R.todo) return true;  // more cells to look at; otherwise finish the cell right away
     }
-    R.skip_visit = false;
-    // nothing at or beyond this cell's exit can beat the best hit / lies inside the grid: done
-    const float lim = fminf(R.tf, R.best + tauS);
+    if (lvl == 2 && R.occ) {
+        // descend into the NOMINAL block's bricks, starting exactly at its entry time (a time slack would slide the
+        // start point along the ray's major axis; the start cell's rounding is covered by the brick walk's probes)
+        R.px = R.cx; R.py = R.cy; R.pz = R.cz;
+        const int lx = R.cx * 8, ly = R.cy * 8, lz = R.cz * 8;
+        enter_level(R, g, inv_vs, 3, lx, ly, lz, lx + 8, ly + 8, lz + 8, fmaxf(R.t_in, R.tn));
+        R.lvl = 1;
+        R.fresh = true;
+        R.occ = false;
+        return true;
+    }
+    // Termination.  Every cell not looked at yet has slab t0 >= t_o - tau(major axis): along the major axis the ray is
+    // monotone and well conditioned, so cells of later major-axis slabs are entered no earlier than t_o - tau_major; cells of
+    // the current slab that are reached through another axis were either flagged as near-ties and looked at just now, or
+    // their crossing is more than the tolerance away.  (The sum of all three taus is NOT needed: one tiny direction
+    // component would make it infinite and force those rays through the whole grid -- the tail of the kernel.)
+    const float lim = fminf(R.tf, R.best + R.tau_term);
     if (!(t_o <= lim)) return false;
     // advance along the exit axis (branch-free: select the axis' operands, compute once, write back)
     const int sh = lvl * 3;
@@ -382,16 +441,19 @@ __device__ __forceinline__ bool step_ray(Lane& R, const GridParams& g, const Tra
     R.emask = ex ? 1 : (ey ? 2 : 4);
     R.tau_ent = tau_exit_adv;
     R.t_in = t_o;
+    R.fresh = true;
     if (out) {
-        // left the block: resume the block level (its plane times are recomputed, not stored) and let it advance on the
-        // next step
+        // left the block: resume the block level (its plane times are recomputed, not stored); the block itself has been
+        // visited already, so it only advances on the next step
         if (lvl == 2) return false;
         R.cx = R.px; R.cy = R.py; R.cz = R.pz;
         axis_planes(R.tMx, R.tPx, R.cx, R.ox, R.dx, R.ix, g.org[0], g.vs, 6);
         axis_planes(R.tMy, R.tPy, R.cy, R.oy, R.dy, R.iy, g.org[1], g.vs, 6);
         axis_planes(R.tMz, R.tPz, R.cz, R.oz, R.dz, R.iz, g.org[2], g.vs, 6);
         R.lvl = 2;
-        R.skip_visit = true;
+        R.fresh = false;
+        R.todo = 0u;
+        R.occ = false;
     }
     return true;
 }
@@ -404,7 +466,7 @@ template <bool PRIMARY, bool WANT_PRIM, bool LDS_M1>
 __global__ __launch_bounds__(256) void k_trace(GridParams g, TraceMips M, const uint32_t* __restrict__ word_prefix, const float* __restrict__ rays,
                                                Camera cam, uint64_t nrays, float tmin, float tmax, float* __restrict__ t_out,
                                                uint32_t* __restrict__ prim_out, vx_hit* __restrict__ hits, unsigned long long* nhits,
-                                               unsigned long long* next_ray, uint32_t m1_words, int kStepsPerRound, int kRefillBelow)
+                                               unsigned long long* next_ray, uint32_t m1_words, int kStepsPerRound, int kRefillBelow, int kItersPerRound)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t m1_lds[];
     if (LDS_M1) {
@@ -418,6 +480,9 @@ __global__ __launch_bounds__(256) void k_trace(GridParams g, TraceMips M, const 
     bool busy = false;       // traversal in progress
     bool drained = false;    // the global counter is exhausted
     int steps_left = 0;      // safety cap per ray
+#ifdef VX_TRACE_DEBUG_CYCLES
+    unsigned long long dbg_t0 = 0;
+#endif
     for (;;) {
         const unsigned long long busy_mask = __ballot(busy);
         const int nbusy = __popcll(busy_mask);
@@ -453,6 +518,9 @@ __global__ __launch_bounds__(256) void k_trace(GridParams g, TraceMips M, const 
                         R.ox = a.x; R.oy = a.y; R.oz = b.x; R.dx = b.y; R.dy = c.x; R.dz = c.y;
                     }
                     busy = setup_ray(R, g, M, inv_vs, tmax);
+#ifdef VX_TRACE_DEBUG_CYCLES
+                    dbg_t0 = wall_clock64();
+#endif
                     steps_left = 1 << 20;
                     if (!busy) {  // cannot touch the grid: retire at once as a miss
                         if (t_out) t_out[r] = -1.0f;
@@ -466,12 +534,23 @@ __global__ __launch_bounds__(256) void k_trace(GridParams g, TraceMips M, const 
             if (drained) break;
             continue;
         }
-        // ---- trace
+        // ---- trace, in two phases so that the wave's lanes run the same code together:
+        // (1) upper-level walk until the lane has an occupied brick pending (or its ray is finished),
+        // (2) the brick test for every lane with a pending brick.
         bool finished = false;
-        if (busy) {
-#pragma unroll 1
+        for (int it = 0; it < kItersPerRound; ++it) {
             for (int k = 0; k < kStepsPerRound; ++k) {
-                if (!step_ray<LDS_M1>(R, g, M, m1_lds, inv_vs, R.tolp, tmin, tmax) || --steps_left <= 0) { finished = true; break; }
+                const bool go = busy && !finished && !R.pending;
+                if (!__ballot(go)) break;
+                if (go) {
+                    if (!upper_step<LDS_M1>(R, g, M, m1_lds, inv_vs) || --steps_left <= 0) finished = true;
+                }
+            }
+            const bool pend = busy && R.pending;
+            if (!__ballot(pend)) break;  // every live lane finished its ray in this round
+            if (pend) {
+                brick_test(R, g, M, inv_vs, R.tolp, R.bx, R.by, R.bz, tmin, tmax);
+                R.pending = false;
             }
         }
         // ---- retire
@@ -487,6 +566,9 @@ __global__ __launch_bounds__(256) void k_trace(GridParams g, TraceMips M, const 
                 } else
                     best_prim = 0;
             }
+#ifdef VX_TRACE_DEBUG_CYCLES
+            best_t = (float)(wall_clock64() - dbg_t0);  // diagnostic build: report the ray's residency in 100 MHz ticks
+#endif
 #ifdef VX_TRACE_DEBUG_STEPS
             best_t = (float)((1 << 20) - steps_left);  // diagnostic build: report the step count instead of t
 #endif
@@ -528,6 +610,7 @@ void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* wo
     // persistent grid: 256 CUs x 4 resident 256-thread workgroups, fewer when there are not that many rays
     static const int env_blocks = getenv("VOXHIP_TRACE_BLOCKS") ? atoi(getenv("VOXHIP_TRACE_BLOCKS")) : 1024;
     static const int env_steps = getenv("VOXHIP_TRACE_STEPS") ? atoi(getenv("VOXHIP_TRACE_STEPS")) : 8;
+    static const int env_iters = getenv("VOXHIP_TRACE_ITERS") ? atoi(getenv("VOXHIP_TRACE_ITERS")) : 4;
     static const int env_refill = getenv("VOXHIP_TRACE_REFILL") ? atoi(getenv("VOXHIP_TRACE_REFILL")) : 44;
     uint64_t nblk = (nrays + 255) / 256;
     if (nblk > (uint64_t)env_blocks) nblk = (uint64_t)env_blocks;
@@ -535,7 +618,7 @@ void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* wo
     const bool want_prim = word_prefix != nullptr;
     const size_t shmem = lds_m1 ? (size_t)m1_words * 4 : 0;
 #define VX_LAUNCH(P, W, L) \
-    VX_KL((k_trace<P, W, L>), grid, block, shmem, s, g, mips, word_prefix, rays, c, nrays, tmin, tmax, t_out, prim_out, hits, nhits, next_ray, m1_words, env_steps, env_refill)
+    VX_KL((k_trace<P, W, L>), grid, block, shmem, s, g, mips, word_prefix, rays, c, nrays, tmin, tmax, t_out, prim_out, hits, nhits, next_ray, m1_words, env_steps, env_refill, env_iters)
 #define VX_LAUNCH2(P, W) do { if (lds_m1) VX_LAUNCH(P, W, true); else VX_LAUNCH(P, W, false); } while (0)
     if (cam) { if (want_prim) VX_LAUNCH2(true, true); else VX_LAUNCH2(true, false); }
     else { if (want_prim) VX_LAUNCH2(false, true); else VX_LAUNCH2(false, false); }
