@@ -169,18 +169,18 @@ struct vx_grid {
     float bbmin[3] = {0, 0, 0}, bbmax[3] = {0, 0, 0}, bbc[3] = {0, 0, 0};
     uint64_t triangles = 0;
     uint32_t cdim[3] = {0, 0, 0}, c2dim[3] = {0, 0, 0};
-    DevBuf words, cwords, c2words, bricks, bbounds, wprefix, recs, units, ubase, btri, umask, hbase, scantmp, small, vec;
+    DevBuf words, cwords, c2words, bricks, bbounds, idxtmp, ttmp, wprefix, recs, units, ubase, btri, umask, hbase, scantmp, small, vec;
     bool coarse_valid = false, prefix_valid = false, counts_valid = true;
     uint64_t occupied = 0, set_calls = 0, host_set_calls = 0;
     uint64_t vec_count = 0;
     void set_dev(int d)
     {
         device = d;
-        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &bbounds, &wprefix, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec}) b->dev = d;
+        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &bbounds, &idxtmp, &ttmp, &wprefix, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec}) b->dev = d;
     }
     void release_all()
     {
-        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &bbounds, &wprefix, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec}) b->release();
+        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &bbounds, &idxtmp, &ttmp, &wprefix, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec}) b->release();
     }
 };
 
@@ -747,7 +747,17 @@ static vx_status trace_common(vx_grid* g, const float* dev_rays, const vx::Camer
 {
     VX_TRY(ensure_coarse(g));
     const uint32_t* prefix = nullptr;
-    if (dev_prim || dev_hits) { VX_TRY(ensure_prefix(g)); prefix = g->wprefix.as<uint32_t>(); }
+    unsigned long long* idx_tmp = nullptr;
+    if (dev_prim || dev_hits) {
+        VX_TRY(ensure_prefix(g));
+        prefix = g->wprefix.as<uint32_t>();
+        VX_HIP(g->idxtmp.ensure((size_t)nrays * 8 + 8));
+        idx_tmp = g->idxtmp.as<unsigned long long>();
+        if (!dev_t) {  // the rank / compaction pass reads t
+            VX_HIP(g->ttmp.ensure((size_t)nrays * 4 + 8));
+            dev_t = g->ttmp.as<float>();
+        }
+    }
     vx::TraceMips mips;
     mips.bricks = g->bricks.as<unsigned long long>();
     mips.bounds = g->bbounds.as<uint32_t>();
@@ -756,7 +766,7 @@ static vx_status trace_common(vx_grid* g, const float* dev_rays, const vx::Camer
     mips.w2 = g->c2words.as<uint32_t>();
     for (int a = 0; a < 3; ++a) { mips.d1[a] = g->cdim[a]; mips.d2[a] = g->c2dim[a]; }
     vx::launch_trace(g->g, mips, prefix, dev_rays, cam, nrays, tmin, tmax, dev_t, dev_prim, dev_hits, (unsigned long long*)dev_nhits,
-                     &g->small.as<Small>()->nhits, g->stream);
+                     &g->small.as<Small>()->nhits, idx_tmp, g->stream);
     VX_HIP(hipGetLastError());
     return VX_OK;
 }

@@ -87,7 +87,8 @@ struct TraceMips {
 };
 void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* word_prefix, const float* rays, const Camera* cam,
                   uint64_t nrays, float tmin, float tmax, float* t_out, uint32_t* prim_out, vx_hit* hits, unsigned long long* nhits,
-                  unsigned long long* next_ray /*device work counter*/, hipStream_t s);
+                  unsigned long long* next_ray /*device work counter*/, unsigned long long* idx_tmp /*nrays x 8 B when prim/hits wanted*/,
+                  hipStream_t s);
 
 // single-voxel helpers
 void launch_set_bit(uint32_t* words, uint64_t idx, hipStream_t s);

@@ -462,11 +462,11 @@ __device__ __forceinline__ bool upper_step(Lane& R, const GridParams& g, const T
 
 // Persistent waves with dynamic ray fetch.  Exit condition every wave reaches: the counter passes nrays (no refill
 // possible) and every lane's ray has finished; each ray finishes in a bounded number of steps.
-template <bool PRIMARY, bool WANT_PRIM, bool LDS_M1>
-__global__ __launch_bounds__(256) void k_trace(GridParams g, TraceMips M, const uint32_t* __restrict__ word_prefix, const float* __restrict__ rays,
-                                               Camera cam, uint64_t nrays, float tmin, float tmax, float* __restrict__ t_out,
-                                               uint32_t* __restrict__ prim_out, vx_hit* __restrict__ hits, unsigned long long* nhits,
-                                               unsigned long long* next_ray, uint32_t m1_words, int kStepsPerRound, int kRefillBelow, int kItersPerRound)
+template <bool PRIMARY, bool LDS_M1>
+__global__ __launch_bounds__(256) void k_trace(GridParams g, TraceMips M, const float* __restrict__ rays, Camera cam, uint64_t nrays, float tmin,
+                                               float tmax, float* __restrict__ t_out, unsigned long long* __restrict__ idx_out,
+                                               unsigned long long* next_ray, uint32_t m1_words, int kStepsPerRound, int kRefillBelow,
+                                               int kItersPerRound, int kChunkRays)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t m1_lds[];
     if (LDS_M1) {
@@ -478,7 +478,10 @@ __global__ __launch_bounds__(256) void k_trace(GridParams g, TraceMips M, const 
     Lane R;
     uint64_t r = ~0ull;      // ray this lane is tracing (~0: none)
     bool busy = false;       // traversal in progress
-    bool drained = false;    // the global counter is exhausted
+    bool drained = false;    // no ray left for this wave: the global counter and the wave's chunk are exhausted
+    bool drained_global = false;
+    const uint64_t kChunk = (uint64_t)kChunkRays;  // rays a wave reserves per touch of the global counter
+    uint64_t chunk_cur = 0, chunk_end = 0;
     int steps_left = 0;      // safety cap per ray
 #ifdef VX_TRACE_DEBUG_CYCLES
     unsigned long long dbg_t0 = 0;
@@ -487,14 +490,29 @@ __global__ __launch_bounds__(256) void k_trace(GridParams g, TraceMips M, const 
         const unsigned long long busy_mask = __ballot(busy);
         const int nbusy = __popcll(busy_mask);
         if (!drained && nbusy < kRefillBelow) {
-            // ---- refill idle lanes
+            // ---- refill idle lanes.  Ray indices come from a per-wave chunk; the global counter is touched once per chunk
+            // (an atomic round trip per refill sat on every round's critical path).
             const unsigned long long idle_mask = ~busy_mask;
-            unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(next_ray, (unsigned long long)(64 - nbusy));
-            base = ((unsigned long long)__shfl((unsigned)(base >> 32), 0, 64) << 32) | __shfl((unsigned)base, 0, 64);
-            if (base + (unsigned long long)(64 - nbusy) >= nrays) drained = true;
+            const uint64_t need = (uint64_t)(64 - nbusy);
+            const uint64_t take = need < chunk_end - chunk_cur ? need : chunk_end - chunk_cur;
+            const uint64_t first = chunk_cur;
+            chunk_cur += take;
+            uint64_t second = 0;
+            if (take < need) {
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(next_ray, (unsigned long long)kChunk);
+                base = ((unsigned long long)__shfl((unsigned)(base >> 32), 0, 64) << 32) | __shfl((unsigned)base, 0, 64);
+                second = base;
+                chunk_cur = base + (need - take);
+                chunk_end = base + kChunk;
+                if (chunk_end > nrays) chunk_end = nrays > base ? nrays : base;
+                if (chunk_cur > chunk_end) chunk_cur = chunk_end;
+                if (base + kChunk >= nrays) drained_global = true;
+            }
+            if (drained_global && chunk_cur >= chunk_end) drained = true;
             if (!busy) {
-                const uint64_t mine = base + __popcll(idle_mask & ((1ull << lane) - 1ull));
+                const uint64_t pos = (uint64_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
+                const uint64_t mine = pos < take ? first + pos : (take < need ? second + (pos - take) : nrays);
                 if (mine < nrays) {
                     r = mine;
                     if (PRIMARY) {
@@ -524,7 +542,7 @@ __global__ __launch_bounds__(256) void k_trace(GridParams g, TraceMips M, const 
                     steps_left = 1 << 20;
                     if (!busy) {  // cannot touch the grid: retire at once as a miss
                         if (t_out) t_out[r] = -1.0f;
-                        if (WANT_PRIM && prim_out) prim_out[r] = 0xFFFFFFFFu;
+                        if (idx_out) idx_out[r] = ~0ull;
                         r = ~0ull;
                     }
                 }
@@ -553,19 +571,10 @@ __global__ __launch_bounds__(256) void k_trace(GridParams g, TraceMips M, const 
                 R.pending = false;
             }
         }
-        // ---- retire
-        float best_t = -1.0f;
-        uint32_t best_prim = 0xFFFFFFFFu;
+        // ---- retire: t and the voxel index of the hit; the primitive rank (two dependent loads) and the hit compaction are
+        // done by k_rank over all rays afterwards, off this kernel's critical path
         if (finished) {
-            if (R.best_idx != ~0ull) {
-                best_t = R.best;
-                if (WANT_PRIM) {
-                    const uint64_t wi = R.best_idx >> 5;
-                    const uint32_t bit = (uint32_t)R.best_idx & 31u;
-                    best_prim = word_prefix[wi] + __popc(M.w0[wi] & ((1u << bit) - 1u));  // rank == gl_PrimitiveID
-                } else
-                    best_prim = 0;
-            }
+            float best_t = R.best_idx != ~0ull ? R.best : -1.0f;
 #ifdef VX_TRACE_DEBUG_CYCLES
             best_t = (float)(wall_clock64() - dbg_t0);  // diagnostic build: report the ray's residency in 100 MHz ticks
 #endif
@@ -573,35 +582,55 @@ __global__ __launch_bounds__(256) void k_trace(GridParams g, TraceMips M, const 
             best_t = (float)((1 << 20) - steps_left);  // diagnostic build: report the step count instead of t
 #endif
             if (t_out) t_out[r] = best_t;
-            if (WANT_PRIM && prim_out) prim_out[r] = best_prim;
+            if (idx_out) idx_out[r] = R.best_idx;
             busy = false;
+            r = ~0ull;
         }
-        if (hits) {
-            // wavefront hit compaction: ballot + prefix popcount, one atomic per wave and retire event
-            const bool hit = finished && best_t > 0.0f;
-            const unsigned long long bal = __ballot(hit);
-            if (bal) {
-                unsigned long long hb = 0;
-                if (lane == 0) hb = atomicAdd(nhits, (unsigned long long)__popcll(bal));
-                hb = ((unsigned long long)__shfl((unsigned)(hb >> 32), 0, 64) << 32) | __shfl((unsigned)hb, 0, 64);
-                if (hit) {
-                    vx_hit h;
-                    h.ray = (uint32_t)r; h.prim = best_prim; h.t = best_t;
-                    hits[hb + __popcll(bal & ((1ull << lane) - 1ull))] = h;
-                }
+    }
+}
+
+// Primitive id (== gl_PrimitiveID: rank of the voxel in the ascending AABB list) and wavefront hit compaction.
+__global__ __launch_bounds__(256) void k_rank(const float* __restrict__ t, const unsigned long long* __restrict__ idx, uint64_t nrays,
+                                              const uint32_t* __restrict__ words, const uint32_t* __restrict__ word_prefix,
+                                              uint32_t* __restrict__ prim_out, vx_hit* __restrict__ hits, unsigned long long* nhits)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const bool active = r < nrays;
+    float tt = -1.0f;
+    uint32_t prim = 0xFFFFFFFFu;
+    if (active) {
+        tt = t[r];
+        const unsigned long long i = idx[r];
+        if (i != ~0ull) {
+            const uint64_t wi = i >> 5;
+            const uint32_t bit = (uint32_t)i & 31u;
+            prim = word_prefix[wi] + __popc(words[wi] & ((1u << bit) - 1u));
+        }
+        if (prim_out) prim_out[r] = prim;
+    }
+    if (hits) {
+        const bool hit = active && prim != 0xFFFFFFFFu;
+        const unsigned long long bal = __ballot(hit);
+        if (bal) {
+            const int lane = threadIdx.x & 63;
+            unsigned long long hb = 0;
+            if (lane == 0) hb = atomicAdd(nhits, (unsigned long long)__popcll(bal));
+            hb = ((unsigned long long)__shfl((unsigned)(hb >> 32), 0, 64) << 32) | __shfl((unsigned)hb, 0, 64);
+            if (hit) {
+                vx_hit h;
+                h.ray = (uint32_t)r; h.prim = prim; h.t = tt;
+                hits[hb + __popcll(bal & ((1ull << lane) - 1ull))] = h;
             }
         }
-        if (finished) r = ~0ull;
     }
 }
 
 void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* word_prefix, const float* rays, const Camera* cam, uint64_t nrays,
                   float tmin, float tmax, float* t_out, uint32_t* prim_out, vx_hit* hits, unsigned long long* nhits, unsigned long long* next_ray,
-                  hipStream_t s)
+                  unsigned long long* idx_tmp, hipStream_t s)
 {
     if (!nrays) return;
-    if (hits && nhits) hipMemsetAsync(nhits, 0, sizeof(unsigned long long), s);
-    hipMemsetAsync(next_ray, 0, sizeof(unsigned long long), s);
+    (void)hipMemsetAsync(next_ray, 0, sizeof(unsigned long long), s);
     Camera c{};
     if (cam) c = *cam;
     const uint64_t n1 = (uint64_t)mips.d1[0] * mips.d1[1] * mips.d1[2];
@@ -611,19 +640,23 @@ void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* wo
     static const int env_blocks = getenv("VOXHIP_TRACE_BLOCKS") ? atoi(getenv("VOXHIP_TRACE_BLOCKS")) : 1024;
     static const int env_steps = getenv("VOXHIP_TRACE_STEPS") ? atoi(getenv("VOXHIP_TRACE_STEPS")) : 8;
     static const int env_iters = getenv("VOXHIP_TRACE_ITERS") ? atoi(getenv("VOXHIP_TRACE_ITERS")) : 4;
+    static const int env_chunk = getenv("VOXHIP_TRACE_CHUNK") ? atoi(getenv("VOXHIP_TRACE_CHUNK")) : 64;
     static const int env_refill = getenv("VOXHIP_TRACE_REFILL") ? atoi(getenv("VOXHIP_TRACE_REFILL")) : 44;
     uint64_t nblk = (nrays + 255) / 256;
     if (nblk > (uint64_t)env_blocks) nblk = (uint64_t)env_blocks;
     const dim3 grid((unsigned)nblk), block(256);
-    const bool want_prim = word_prefix != nullptr;
+    const bool want_rank = (prim_out || hits) && word_prefix && idx_tmp;
+    unsigned long long* idx_out = want_rank ? idx_tmp : nullptr;
     const size_t shmem = lds_m1 ? (size_t)m1_words * 4 : 0;
-#define VX_LAUNCH(P, W, L) \
-    VX_KL((k_trace<P, W, L>), grid, block, shmem, s, g, mips, word_prefix, rays, c, nrays, tmin, tmax, t_out, prim_out, hits, nhits, next_ray, m1_words, env_steps, env_refill, env_iters)
-#define VX_LAUNCH2(P, W) do { if (lds_m1) VX_LAUNCH(P, W, true); else VX_LAUNCH(P, W, false); } while (0)
-    if (cam) { if (want_prim) VX_LAUNCH2(true, true); else VX_LAUNCH2(true, false); }
-    else { if (want_prim) VX_LAUNCH2(false, true); else VX_LAUNCH2(false, false); }
-#undef VX_LAUNCH2
+#define VX_LAUNCH(P, L) \
+    VX_KL((k_trace<P, L>), grid, block, shmem, s, g, mips, rays, c, nrays, tmin, tmax, t_out, idx_out, next_ray, m1_words, env_steps, env_refill, env_iters, env_chunk)
+    if (cam) { if (lds_m1) VX_LAUNCH(true, true); else VX_LAUNCH(true, false); }
+    else { if (lds_m1) VX_LAUNCH(false, true); else VX_LAUNCH(false, false); }
 #undef VX_LAUNCH
+    if (want_rank) {
+        if (hits && nhits) (void)hipMemsetAsync(nhits, 0, sizeof(unsigned long long), s);
+        VX_KL(k_rank, dim3((unsigned)((nrays + 255) / 256)), block, 0, s, t_out, idx_tmp, nrays, mips.w0, word_prefix, prim_out, hits, nhits);
+    }
 }
 
 }  // namespace vx
