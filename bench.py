@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--rays", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-ray-sample", type=int, default=1500)
+    ap.add_argument("--flavour", default="vec", choices=["vec", "bool"],
+                    help="vec: VoxelGridVec build (BASELINE configs[2]); bool: VoxelGridBool build + K4 getAabbs (the app's default path)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; the driver's multi-GPU runs) or gloo (rehearsal)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses device 0")
     return ap.parse_args()
@@ -95,7 +97,7 @@ def main():
     d_prim = torch.empty(a.rays, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
 
-    kind = voxhip.GRID_VEC if world == 1 else voxhip.GRID_BOOL
+    kind = voxhip.GRID_VEC if (world == 1 and a.flavour == "vec") else voxhip.GRID_BOOL
     grid = voxhip.Grid.voxelize(mesh, vs, kind)  # sizes the handle's buffers (untimed)
     desc = grid.describe()
     nwords = desc["num_words"]
@@ -200,8 +202,8 @@ def main():
         "metric": "Mrays/s", "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "%s (%d tris) @ %d^3 grid, VoxelGridVec build + VoxelGridBool getAabbs + %d random rays per GPU"
-                   % (a.scene, T, a.grid, R), "grid_dim": list(desc["dim"]), "voxel_size": float(vs), "rays_per_gpu": R,
+        "config": {"workload": "%s (%d tris) @ %d^3 grid, %s + %d random rays per GPU"
+                   % (a.scene, T, a.grid, "VoxelGridVec build + getAabbs" if kind == voxhip.GRID_VEC else "VoxelGridBool build + getAabbs", R), "grid_dim": list(desc["dim"]), "voxel_size": float(vs), "rays_per_gpu": R,
                    "parallelism": "1 GPU" if world == 1 else "bitmask word-shards x%d + RCCL all-gather, rays independent" % world},
         "mvoxels_per_s": round(N / (stage_ms[0] * 1e-3) / 1e6, 1),
         "mrays_per_s_trace_stage": round(R * world / (stage_ms[3] * 1e-3) / 1e6, 1),

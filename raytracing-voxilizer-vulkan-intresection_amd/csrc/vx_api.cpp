@@ -278,21 +278,39 @@ vx_status run_setup(const vx_mesh* m, const vx::GridParams& g, int sat, uint64_t
     return VX_OK;
 }
 
-vx_status ensure_prefix(vx_grid* g)
+// word_prefix + occupied count.  Split in two so that callers can queue dependent kernels before the host waits for the
+// count (a host sync in front of a kernel leaves the GPU idle and the clocks down for its start).
+vx_status prefix_launch(vx_grid* g, bool* pending)
 {
+    *pending = false;
     if (g->prefix_valid) return VX_OK;
-    DeviceGuard dg(g->device);
     VX_HIP(g->wprefix.ensure((size_t)(g->g.nwords + 2) * 4));
     VX_HIP(g->scantmp.ensure(vx::scan_tmp_bytes(g->g.nwords)));
     Small* ds = g->small.as<Small>();
     vx::launch_scan_u32(g->words.as<uint32_t>(), g->wprefix.as<uint32_t>(), g->g.nwords, true, g->scantmp.p, &ds->total_b, g->stream);
+    *pending = true;
+    return VX_OK;
+}
+
+vx_status prefix_finish(vx_grid* g, bool pending)
+{
+    if (!pending) return VX_OK;
     unsigned long long tot = 0;
-    VX_HIP(hipMemcpyAsync(&tot, &ds->total_b, 8, hipMemcpyDeviceToHost, g->stream));
+    VX_HIP(hipMemcpyAsync(&tot, &g->small.as<Small>()->total_b, 8, hipMemcpyDeviceToHost, g->stream));
     VX_HIP(hipStreamSynchronize(g->stream));
     if (tot >= 0xFFFFFFFFull) return fail(VX_ERR_CAPACITY, "more than 2^32 occupied voxels");
     g->occupied = tot;
     g->prefix_valid = true;
     return VX_OK;
+}
+
+vx_status ensure_prefix(vx_grid* g)
+{
+    if (g->prefix_valid) return VX_OK;
+    DeviceGuard dg(g->device);
+    bool pending = false;
+    VX_TRY(prefix_launch(g, &pending));
+    return prefix_finish(g, pending);
 }
 
 vx_status ensure_coarse(vx_grid* g)
@@ -698,10 +716,13 @@ vx_status vx_grid_aabbs_device(const vx_grid* gc, vx_aabb* dev_out, uint64_t cap
         if (n && dev_out) VX_HIP(hipMemcpyAsync(dev_out, g->vec.p, (size_t)n * sizeof(vx_aabb), hipMemcpyDeviceToDevice, g->stream));
         return VX_OK;
     }
-    VX_TRY(ensure_prefix(g));
-    if (count) *count = g->occupied;
-    if (cap && dev_out && g->occupied)
+    // queue the prefix scan and the emission back to back, then wait once for the count
+    bool pending = false;
+    VX_TRY(prefix_launch(g, &pending));
+    if (cap && dev_out && (pending || g->occupied))
         vx::launch_emit_bool_aabbs(g->words.as<uint32_t>(), g->wprefix.as<uint32_t>(), g->g, dev_out, cap, g->stream);
+    VX_TRY(prefix_finish(g, pending));
+    if (count) *count = g->occupied;
     VX_HIP(hipGetLastError());
     return VX_OK;
 }
