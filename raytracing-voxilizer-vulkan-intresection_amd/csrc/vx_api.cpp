@@ -194,8 +194,8 @@ struct vx_octree {
     uint64_t max_items = 16;
     uint64_t nitems = 0;
     DevBuf items;  // sorted Morton codes
-    std::vector<vx_octree_node> nodes;
-    bool built_tree = false;
+    vx_octree_node* dnodes = nullptr;  // pre-order node array (device, hipMalloc)
+    uint64_t nnodes = 0;
 };
 
 namespace {
@@ -854,28 +854,6 @@ vx_status vx_trace(const vx_grid* gc, const float* host_rays, uint64_t nrays, fl
 }
 
 // ---- octree ---------------------------------------------------------------------------------------------------
-static uint32_t build_node_host(vx_octree* o, const uint64_t* items, uint32_t begin, uint32_t end, uint32_t depth)
-{
-    // octTree.hpp:319-358 (node numbering is pre-order; children hold indices into the node array)
-    const uint32_t ni = (uint32_t)o->nodes.size();
-    o->nodes.emplace_back();
-    o->nodes[ni].start = begin;
-    o->nodes[ni].count = end - begin;
-    for (int c = 0; c < 8; ++c) o->nodes[ni].children[c] = 0xFFFFFFFFu;
-    if (depth >= o->bits || (uint64_t)(end - begin) <= o->max_items) return ni;
-    const uint32_t shift = 3 * (o->bits - 1 - depth);
-    uint32_t cur = begin;
-    for (int child = 0; child < 8; ++child) {
-        if (cur >= end) break;
-        const uint32_t cb = cur;
-        while (cur < end && (int)((items[cur] >> shift) & 7u) == child) ++cur;
-        if (cb == cur) continue;
-        const uint32_t ci = build_node_host(o, items, cb, cur, depth + 1);
-        o->nodes[ni].children[child] = ci;
-    }
-    return ni;
-}
-
 vx_status vx_octree_build(const vx_mesh* mesh_c, float vs, uint64_t max_items, void* stream, vx_octree** out)
 {
     if (!mesh_c || !out) return fail(VX_ERR_INVALID_ARG, "null argument");
@@ -894,7 +872,7 @@ vx_status vx_octree_build(const vx_mesh* mesh_c, float vs, uint64_t max_items, v
     DevBuf small, recs, units, ubase, btri, scantmp, umask, hbase, unsorted, sorttmp;
     for (DevBuf* b : {&small, &recs, &units, &ubase, &btri, &scantmp, &umask, &hbase, &unsorted, &sorttmp}) b->dev = o->device;
     auto cleanup = [&]() { for (DevBuf* b : {&small, &recs, &units, &ubase, &btri, &scantmp, &umask, &hbase, &unsorted, &sorttmp}) b->release(); };
-    auto bail = [&](vx_status st) { cleanup(); o->items.release(); delete o; return st; };
+    auto bail = [&](vx_status st) { cleanup(); o->items.release(); if (o->dnodes) (void)hipFree(o->dnodes); delete o; return st; };
 #define OCT_HIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return bail(fail(VX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__))); } while (0)
 #define OCT_TRY(expr) do { vx_status s__ = (expr); if (s__ != VX_OK) return bail(s__); } while (0)
     OCT_HIP(small.ensure(sizeof(Small)));
@@ -928,7 +906,6 @@ vx_status vx_octree_build(const vx_mesh* mesh_c, float vs, uint64_t max_items, v
         if (hits >= 0xFFFFFFFFull) return bail(fail(VX_ERR_CAPACITY, "more than 2^32 octree items"));
     }
     o->nitems = hits;
-    std::vector<uint64_t> host_items((size_t)hits);
     if (hits) {
         OCT_HIP(unsorted.ensure((size_t)hits * 8));
         OCT_HIP(o->items.ensure((size_t)hits * 8));
@@ -936,14 +913,10 @@ vx_status vx_octree_build(const vx_mesh* mesh_c, float vs, uint64_t max_items, v
                               nullptr, unsorted.as<uint64_t>(), s);
         const size_t tb = vx::sort_tmp_bytes(hits);
         OCT_HIP(sorttmp.ensure(tb));
-        vx::launch_sort_u64(unsorted.as<uint64_t>(), o->items.as<uint64_t>(), hits, (int)(3 * o->bits ? 3 * o->bits : 1), sorttmp.p, tb, s);
-        OCT_HIP(hipMemcpyAsync(host_items.data(), o->items.p, (size_t)hits * 8, hipMemcpyDeviceToHost, s));
-        OCT_HIP(hipStreamSynchronize(s));
+        vx::launch_sort_u64(unsorted.as<uint64_t>(), o->items.as<uint64_t>(), hits, (int)(3 * o->bits ? 3 * o->bits : 1), sorttmp.p, tb, s);  // octTree.hpp:363
     }
-    // node array (pre-order DFS).  TODO(next): device-parallel construction from segment boundaries per depth.
-    o->nodes.reserve(std::max<size_t>(1, (size_t)hits / 4));
-    build_node_host(o, host_items.data(), 0, (uint32_t)hits, 0);
-    o->built_tree = true;
+    // node array: breadth-first expansion + pre-order renumbering on the device (octTree.hpp:319-358, :371)
+    OCT_HIP(vx::build_octree_nodes(o->items.as<uint64_t>(), (uint32_t)hits, o->bits, max_items, &o->dnodes, &o->nnodes, s));
     cleanup();
 #undef OCT_HIP
 #undef OCT_TRY
@@ -952,8 +925,8 @@ vx_status vx_octree_build(const vx_mesh* mesh_c, float vs, uint64_t max_items, v
 }
 
 uint64_t vx_octree_num_items(const vx_octree* o) { return o ? o->nitems : 0; }
-uint64_t vx_octree_num_nodes(const vx_octree* o) { return o ? o->nodes.size() : 0; }
-uint64_t vx_octree_bytes(const vx_octree* o) { return o ? o->nitems * 8 + (uint64_t)o->nodes.size() * 40 : 0; }
+uint64_t vx_octree_num_nodes(const vx_octree* o) { return o ? o->nnodes : 0; }
+uint64_t vx_octree_bytes(const vx_octree* o) { return o ? o->nitems * 8 + o->nnodes * 40 : 0; }
 
 vx_status vx_octree_items(const vx_octree* o, uint64_t* host, uint64_t cap)
 {
@@ -969,8 +942,11 @@ vx_status vx_octree_items(const vx_octree* o, uint64_t* host, uint64_t cap)
 vx_status vx_octree_nodes(const vx_octree* o, vx_octree_node* host, uint64_t cap)
 {
     if (!o || (!host && cap)) return fail(VX_ERR_INVALID_ARG, "null argument");
-    if (cap < o->nodes.size()) return fail(VX_ERR_CAPACITY, "node buffer too small");
-    if (!o->nodes.empty()) std::memcpy(host, o->nodes.data(), o->nodes.size() * sizeof(vx_octree_node));
+    if (cap < o->nnodes) return fail(VX_ERR_CAPACITY, "node buffer too small");
+    if (!o->nnodes) return VX_OK;
+    DeviceGuard dg(o->device);
+    VX_HIP(hipMemcpyAsync(host, o->dnodes, (size_t)o->nnodes * sizeof(vx_octree_node), hipMemcpyDeviceToHost, o->stream));
+    VX_HIP(hipStreamSynchronize(o->stream));
     return VX_OK;
 }
 
@@ -985,7 +961,7 @@ vx_status vx_octree_root_bounds(const vx_octree* o, float mn[3], float mx[3])
 vx_status vx_octree_aabbs_device(const vx_octree* o, vx_aabb* dev_out, uint64_t cap, uint64_t* count)
 {
     if (!o) return fail(VX_ERR_INVALID_ARG, "null argument");
-    const uint64_t n = o->nodes.empty() ? 0 : o->nitems;  // octTree.hpp:505-507
+    const uint64_t n = o->nnodes == 0 ? 0 : o->nitems;  // octTree.hpp:505-507
     if (count) *count = n;
     const uint64_t m = cap < n ? cap : n;
     if (!m || !dev_out) return VX_OK;
@@ -998,7 +974,7 @@ vx_status vx_octree_aabbs_device(const vx_octree* o, vx_aabb* dev_out, uint64_t 
 vx_status vx_octree_aabbs(const vx_octree* o, vx_aabb* host_out, uint64_t cap, uint64_t* count)
 {
     if (!o) return fail(VX_ERR_INVALID_ARG, "null argument");
-    const uint64_t n = o->nodes.empty() ? 0 : o->nitems;
+    const uint64_t n = o->nnodes == 0 ? 0 : o->nitems;
     if (count) *count = n;
     const uint64_t m = cap < n ? cap : n;
     if (!m || !host_out) return VX_OK;
@@ -1018,6 +994,7 @@ void vx_octree_free(vx_octree* o)
 {
     if (!o) return;
     o->items.release();
+    if (o->dnodes) { DeviceGuard dg(o->device); (void)hipFree(o->dnodes); }
     delete o;
 }
 

@@ -97,4 +97,8 @@ void launch_set_bit(uint32_t* words, uint64_t idx, hipStream_t s);
 size_t sort_tmp_bytes(uint64_t n);
 void launch_sort_u64(uint64_t* keys_in, uint64_t* keys_out, uint64_t n, int bits, void* tmp, size_t tmp_bytes, hipStream_t s);
 
+// Octree node array (pre-order, octTree.hpp:319-358) built on the device from the sorted items; *nodes_out is hipMalloc'ed.
+hipError_t build_octree_nodes(const uint64_t* items, uint32_t nitems, uint32_t max_depth, uint64_t max_items, vx_octree_node** nodes_out,
+                              uint64_t* nnodes_out, hipStream_t s);
+
 }  // namespace vx

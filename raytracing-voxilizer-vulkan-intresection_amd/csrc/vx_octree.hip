@@ -1,0 +1,220 @@
+// vx_octree.hip -- device construction of the octree's flat node array from the sorted Morton items
+// (replaces Octree::buildNodeRecursive, octTree.hpp:319-358).
+//
+// The reference recurses depth-first: node = {children[8], start, count}, leaf iff depth >= maxDepth || count <= maxItems,
+// child octant = (code >> 3*(maxDepth-1-depth)) & 7, nodes appended in PRE-ORDER.  Here the tree is expanded breadth-first,
+// one level per pass (every node of a level splits its item range with seven binary searches), and the pre-order numbering
+// is recovered afterwards: in pre-order a node precedes exactly the nodes with a larger (start, depth) pair -- a node's
+// subtree is a contiguous item range, children are visited in ascending start, and nested nodes with equal start are
+// visited shallower first -- so the pre-order index is the rank of the key (start << 8 | depth), obtained with one radix
+// sort of (key, breadth-first id) pairs; child links are then remapped through the inverse permutation.
+#include "vx_internal.h"
+
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace vx {
+
+#define VX_KL(kern, grid, block, shmem, stream, ...)                         \
+    do {                                                                     \
+        ProfScope ps_(#kern, stream);                                        \
+        hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__);   \
+    } while (0)
+
+namespace {
+
+// first position in [lo, hi) whose octant at `shift` is >= c
+__device__ __forceinline__ uint32_t octant_lower_bound(const uint64_t* __restrict__ items, uint32_t lo, uint32_t hi, uint32_t shift, uint32_t c)
+{
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if ((uint32_t)((items[mid] >> shift) & 7ull) < c) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// pass A: number of non-empty children of every node of the level (0 for leaves)
+__global__ __launch_bounds__(256) void k_oct_count(const uint64_t* __restrict__ items, const uint32_t* __restrict__ start, const uint32_t* __restrict__ count,
+                                                   uint32_t nnodes, uint32_t depth, uint32_t max_depth, uint32_t max_items, uint32_t* __restrict__ nchild)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= nnodes) return;
+    const uint32_t s = start[i], n = count[i];
+    uint32_t k = 0;
+    if (depth < max_depth && n > max_items) {  // octTree.hpp:329
+        const uint32_t shift = 3u * (max_depth - 1u - depth);
+        uint32_t prev = s;
+        for (uint32_t c = 1; c <= 8; ++c) {
+            const uint32_t b = c == 8 ? s + n : octant_lower_bound(items, prev, s + n, shift, c);
+            k += b > prev;
+            prev = b;
+        }
+    }
+    nchild[i] = k;
+}
+
+// pass B: write the children into the next level and link them (breadth-first ids)
+__global__ __launch_bounds__(256) void k_oct_emit(const uint64_t* __restrict__ items, uint32_t* __restrict__ start, uint32_t* __restrict__ count,
+                                                  uint32_t* __restrict__ children /*8 per node*/, uint8_t* __restrict__ depth_of, uint32_t level_off,
+                                                  uint32_t nnodes, uint32_t depth, uint32_t max_depth, uint32_t max_items,
+                                                  const uint32_t* __restrict__ child_base, uint32_t next_off)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= nnodes) return;
+    const uint32_t id = level_off + i;
+    const uint32_t s = start[id], n = count[id];
+    depth_of[id] = (uint8_t)depth;
+    uint32_t ch[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) ch[c] = 0xFFFFFFFFu;
+    if (depth < max_depth && n > max_items) {
+        const uint32_t shift = 3u * (max_depth - 1u - depth);
+        uint32_t prev = s, k = child_base[i];
+        for (uint32_t c = 1; c <= 8; ++c) {
+            const uint32_t b = c == 8 ? s + n : octant_lower_bound(items, prev, s + n, shift, c);
+            if (b > prev) {
+                const uint32_t cid = next_off + k++;
+                start[cid] = prev;
+                count[cid] = b - prev;
+                ch[c - 1] = cid;
+            }
+            prev = b;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) children[(size_t)id * 8 + c] = ch[c];
+}
+
+__global__ __launch_bounds__(256) void k_oct_keys(const uint32_t* __restrict__ start, const uint8_t* __restrict__ depth_of, uint32_t n, uint64_t* __restrict__ keys,
+                                                  uint32_t* __restrict__ ids)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = ((uint64_t)start[i] << 8) | depth_of[i];
+    ids[i] = i;
+}
+
+__global__ __launch_bounds__(256) void k_oct_inverse(const uint32_t* __restrict__ order, uint32_t n, uint32_t* __restrict__ newidx)
+{
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r < n) newidx[order[r]] = r;
+}
+
+__global__ __launch_bounds__(256) void k_oct_finalize(const uint32_t* __restrict__ order, const uint32_t* __restrict__ newidx, const uint32_t* __restrict__ start,
+                                                      const uint32_t* __restrict__ count, const uint32_t* __restrict__ children, uint32_t n,
+                                                      vx_octree_node* __restrict__ out)
+{
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= n) return;
+    const uint32_t id = order[r];
+    vx_octree_node nd;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const uint32_t ch = children[(size_t)id * 8 + c];
+        nd.children[c] = ch == 0xFFFFFFFFu ? 0xFFFFFFFFu : newidx[ch];
+    }
+    nd.start = start[id];
+    nd.count = count[id];
+    out[r] = nd;
+}
+
+struct Buf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+hipError_t grow(Buf& b, size_t keep_bytes, size_t need_bytes, hipStream_t s)
+{
+    if (need_bytes <= b.cap) return hipSuccess;
+    size_t ncap = b.cap ? b.cap : 4096;
+    while (ncap < need_bytes) ncap *= 2;
+    void* np = nullptr;
+    hipError_t e = hipMalloc(&np, ncap);
+    if (e != hipSuccess) return e;
+    if (b.p && keep_bytes) {
+        e = hipMemcpyAsync(np, b.p, keep_bytes, hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    if (b.p) (void)hipFree(b.p);
+    b.p = np;
+    b.cap = ncap;
+    return e;
+}
+
+}  // namespace
+
+// Builds the node array on the device.  items: sorted Morton codes (device).  On success *nodes_out is a hipMalloc'ed array
+// of *nnodes_out nodes (the caller frees it with hipFree).
+hipError_t build_octree_nodes(const uint64_t* items, uint32_t nitems, uint32_t max_depth, uint64_t max_items_, vx_octree_node** nodes_out,
+                              uint64_t* nnodes_out, hipStream_t s)
+{
+    const uint32_t max_items = max_items_ > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)max_items_;
+    Buf start, count, children, depth_of, nchild, cbase, tmp;
+    hipError_t e = hipSuccess;
+    auto cleanup = [&]() { for (Buf* b : {&start, &count, &children, &depth_of, &nchild, &cbase, &tmp}) if (b->p) (void)hipFree(b->p); };
+#define OC(expr) do { e = (expr); if (e != hipSuccess) { cleanup(); return e; } } while (0)
+    uint32_t total = 1, level_off = 0, level_n = 1;
+    OC(grow(start, 0, 4096, s));
+    OC(grow(count, 0, 4096, s));
+    OC(grow(children, 0, 4096 * 8, s));
+    OC(grow(depth_of, 0, 4096, s));
+    const uint32_t root[2] = {0u, nitems};
+    OC(hipMemcpyAsync(start.p, &root[0], 4, hipMemcpyHostToDevice, s));
+    OC(hipMemcpyAsync(count.p, &root[1], 4, hipMemcpyHostToDevice, s));
+    for (uint32_t depth = 0;; ++depth) {
+        // pass A + scan -> size of the next level
+        OC(grow(nchild, 0, ((size_t)level_n + 1) * 4, s));
+        OC(grow(cbase, 0, ((size_t)level_n + 2) * 4, s));
+        OC(grow(tmp, 0, scan_tmp_bytes(level_n) + 16, s));
+        VX_KL(k_oct_count, dim3((level_n + 255) / 256), dim3(256), 0, s, items, (const uint32_t*)start.p + level_off, (const uint32_t*)count.p + level_off, level_n,
+              depth, max_depth, max_items, (uint32_t*)nchild.p);
+        unsigned long long* tot_dev = (unsigned long long*)((char*)tmp.p + scan_tmp_bytes(level_n));
+        launch_scan_u32((const uint32_t*)nchild.p, (uint32_t*)cbase.p, level_n, false, tmp.p, tot_dev, s);
+        unsigned long long next_n = 0;
+        OC(hipMemcpyAsync(&next_n, tot_dev, 8, hipMemcpyDeviceToHost, s));
+        OC(hipStreamSynchronize(s));
+        if ((unsigned long long)total + next_n >= 0xFFFFFFFFull) { cleanup(); return hipErrorOutOfMemory; }
+        const uint32_t next_off = total;
+        const size_t need = (size_t)total + next_n;
+        OC(grow(start, (size_t)total * 4, need * 4, s));
+        OC(grow(count, (size_t)total * 4, need * 4, s));
+        OC(grow(children, (size_t)total * 32, need * 32, s));
+        OC(grow(depth_of, (size_t)total, need, s));
+        VX_KL(k_oct_emit, dim3((level_n + 255) / 256), dim3(256), 0, s, items, (uint32_t*)start.p, (uint32_t*)count.p, (uint32_t*)children.p, (uint8_t*)depth_of.p,
+              level_off, level_n, depth, max_depth, max_items, (const uint32_t*)cbase.p, next_off);
+        if (next_n == 0) break;
+        level_off = next_off;
+        level_n = (uint32_t)next_n;
+        total += level_n;
+    }
+    // pre-order numbering: rank of (start << 8 | depth)
+    Buf keys, keys2, ids, order, newidx, sorttmp;
+    auto cleanup2 = [&]() { for (Buf* b : {&keys, &keys2, &ids, &order, &newidx, &sorttmp}) if (b->p) (void)hipFree(b->p); };
+#define OC2(expr) do { e = (expr); if (e != hipSuccess) { cleanup2(); cleanup(); return e; } } while (0)
+    OC2(grow(keys, 0, (size_t)total * 8, s));
+    OC2(grow(keys2, 0, (size_t)total * 8, s));
+    OC2(grow(ids, 0, (size_t)total * 4, s));
+    OC2(grow(order, 0, (size_t)total * 4, s));
+    OC2(grow(newidx, 0, (size_t)total * 4, s));
+    VX_KL(k_oct_keys, dim3((total + 255) / 256), dim3(256), 0, s, (const uint32_t*)start.p, (const uint8_t*)depth_of.p, total, (uint64_t*)keys.p, (uint32_t*)ids.p);
+    size_t tb = 0;
+    OC2(rocprim::radix_sort_pairs(nullptr, tb, (const uint64_t*)keys.p, (uint64_t*)keys2.p, (const uint32_t*)ids.p, (uint32_t*)order.p, (size_t)total, 0u, 40u, s));
+    OC2(grow(sorttmp, 0, tb ? tb : 16, s));
+    OC2(rocprim::radix_sort_pairs(sorttmp.p, tb, (const uint64_t*)keys.p, (uint64_t*)keys2.p, (const uint32_t*)ids.p, (uint32_t*)order.p, (size_t)total, 0u, 40u, s));
+    VX_KL(k_oct_inverse, dim3((total + 255) / 256), dim3(256), 0, s, (const uint32_t*)order.p, total, (uint32_t*)newidx.p);
+    vx_octree_node* out = nullptr;
+    OC2(hipMalloc((void**)&out, (size_t)total * sizeof(vx_octree_node)));
+    VX_KL(k_oct_finalize, dim3((total + 255) / 256), dim3(256), 0, s, (const uint32_t*)order.p, (const uint32_t*)newidx.p, (const uint32_t*)start.p,
+          (const uint32_t*)count.p, (const uint32_t*)children.p, total, out);
+    e = hipStreamSynchronize(s);
+    cleanup2();
+    cleanup();
+    if (e != hipSuccess) { (void)hipFree(out); return e; }
+    *nodes_out = out;
+    *nnodes_out = total;
+    return hipSuccess;
+#undef OC
+#undef OC2
+}
+
+}  // namespace vx
