@@ -354,3 +354,53 @@ def test_revoxelize_reuses_handle(gpu):
     assert np.array_equal(g.bitmask(), ow)
     g.revoxelize(mesh, 0.09)
     assert np.array_equal(g.bitmask(), a)       # idempotent
+
+
+# ---------------------------------------------------------------------------------------------- randomised parity
+def test_random_soups_property(gpu):
+    """Property test (seeded, the oracle is the checker): random triangle soups with random sizes, offsets (grid origins with
+    both signs, non-multiple-of-32 dimensions) and voxel sizes -- bitmask, Vec order and octree items must match."""
+    rng = np.random.default_rng(20260104)
+    for case in range(24):
+        n = int(rng.integers(1, 400))
+        scale = float(10.0 ** rng.uniform(-2, 2))
+        off = rng.uniform(-3, 3, 3) * scale
+        v = (rng.uniform(0, 1, (3 * n, 3)) * scale * rng.uniform(0.05, 1.0, 3) + off).astype(np.float32)
+        t = np.arange(3 * n, dtype=np.int32).reshape(-1, 3)
+        if case % 3 == 0:   # shared vertices, fan
+            t = np.stack([np.zeros(n, np.int32), rng.integers(0, 3 * n, n).astype(np.int32), rng.integers(0, 3 * n, n).astype(np.int32)], 1)
+        ext = float((v.max(0) - v.min(0)).max())
+        vs = np.float32(ext / float(rng.integers(3, 70)))
+        mesh = gpu.Mesh.from_arrays(v, t)
+        sat = case % 2
+        g = gpu.Grid.voxelize(mesh, vs, gpu.GRID_VEC, sat_variant=sat)
+        ow, calls, gi = oracle.build_bool(v, t, vs, threads=0, sat=sat)
+        assert g.describe()["dim"] == gi["dim"], (case, g.describe()["dim"], gi["dim"])
+        assert np.array_equal(g.bitmask(), ow), "case %d bitmask" % case
+        assert g.aabbs().tobytes() == oracle.build_vec(v, t, vs, threads=0, sat=sat).tobytes(), "case %d vec" % case
+        if sat == 0:
+            mi = int(rng.integers(1, 20))
+            o = gpu.Octree(mesh, vs, mi)
+            r = oracle.octree(v, t, vs, max_items=mi, threads=1)
+            assert np.array_equal(o.items(), r["items"]) and o.nodes().tobytes() == r["nodes"].tobytes(), "case %d octree" % case
+        gb = gpu.Grid.voxelize(mesh, vs, gpu.GRID_BOOL, sat_variant=sat)
+        oa = oracle.bool_aabbs(ow, gi, vs)
+        assert gb.aabbs().tobytes() == oa.tobytes(), "case %d aabbs" % case
+        if len(oa):
+            rays = vx_scenes.random_rays(1500, gi["bmin"], gi["bmin"] + np.array(gi["dim"], np.float32) * vs, seed=case)
+            tt, pp, _ = gb.trace(rays)
+            ot, op = oracle.trace_brute(oa, rays)
+            assert np.array_equal(tt, ot) and np.array_equal(pp, op), "case %d rays" % case
+
+
+def test_soup_200k_at_512(gpu):
+    """Mid-size soup at full 512^3 resolution against the (threaded) oracle: bitmask + octree items + node array."""
+    v, t = vx_scenes.soup(200_000, seed=9, edge=0.006)
+    vs = np.float32(1.0 / 512)
+    mesh = gpu.Mesh.from_arrays(v, t)
+    g = gpu.Grid.voxelize(mesh, vs, sat_variant=1)
+    ow, calls, gi = oracle.build_bool(v, t, vs, threads=16)
+    assert np.array_equal(g.bitmask(), ow) and g.describe()["set_calls"] == calls
+    o = gpu.Octree(mesh, vs)
+    r = oracle.octree(v, t, vs, threads=16)
+    assert np.array_equal(o.items(), r["items"]) and o.nodes().tobytes() == r["nodes"].tobytes()

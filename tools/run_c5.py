@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""BASELINE configs[4] at full size: synthetic 10M-triangle soup, 2048^3 grid, Octree (sparse) path, 100M coherent primary
+rays (10 tiles of 10000x1000 pixels from the reference camera model).  Prints timings and checks size-independent properties
+(the brute-force oracle cannot run at this size): sortedness, item/occupancy consistency, a sampled oracle subset check,
+and per-hit self-consistency of t with the rint formula."""
+import os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "raytracing-voxilizer-vulkan-intresection_amd"), os.path.join(ROOT, "oracle")]
+import numpy as np, voxhip, vx_scenes, oracle
+
+NT = int(os.environ.get("C5_TRIS", 10_000_000)); G = int(os.environ.get("C5_GRID", 2048)); TILES = int(os.environ.get("C5_TILES", 10))
+def log(*a): print("[c5 %.1fs]" % (time.time() - T0), *a, flush=True)
+T0 = time.time()
+v, t = vx_scenes.soup(NT, seed=4, edge=1.5 / G)
+vs = np.float32(1.0 / G)
+log("soup", v.shape, t.shape)
+dev = torch.device("cuda", 0)
+dv, dt_ = torch.from_numpy(v).to(dev), torch.from_numpy(t).to(dev)
+mesh = voxhip.Mesh.from_device(dv.data_ptr(), len(v), dt_.data_ptr(), len(t), keep=(dv, dt_))
+torch.cuda.synchronize()
+t0 = time.time(); g = voxhip.Grid.voxelize(mesh, vs, voxhip.GRID_BOOL); d = g.describe(); t1 = time.time()
+log("VoxelGridBool build %.3f s: dim %s occupied %d set_calls %d  -> %.0f Mvoxels/s" % (t1 - t0, d["dim"], d["occupied"], d["set_calls"], np.prod(d["dim"]) / (t1 - t0) / 1e6))
+t0 = time.time(); g.revoxelize(mesh, vs); d = g.describe(); t1 = time.time()
+log("  (steady state, buffers reused) %.3f s -> %.0f Mvoxels/s" % (t1 - t0, np.prod(d["dim"]) / (t1 - t0) / 1e6))
+t0 = time.time(); o = voxhip.Octree(mesh, vs); t1 = time.time()
+log("Octree build %.3f s: items %d nodes %d bytes %d" % (t1 - t0, o.num_items, o.num_nodes, o.memory_bytes()))
+assert o.num_items == d["set_calls"], "octree items must equal the number of setVoxel calls (duplicates kept)"
+items = o.items()
+assert np.all(items[:-1] <= items[1:]), "items not sorted"
+nuniq = int((np.diff(items) != 0).sum()) + 1
+assert nuniq == d["occupied"], (nuniq, d["occupied"])
+assert o.memory_bytes() == 8 * o.num_items + 40 * o.num_nodes
+log("octree properties ok: sorted, unique(items) == occupied == %d" % nuniq)
+# sampled oracle: the hits of a random 0.2 % of the triangles must all be set in the GPU bitmask (and be the same cells)
+rng = np.random.default_rng(5); sel = np.sort(rng.choice(NT, 20000, replace=False))
+gi = oracle.grid_info(v, vs)
+assert gi["dim"] == d["dim"]
+sub_t = t[sel]
+# oracle on the subset but with the FULL mesh's bbox: append two far-apart degenerate triangles? simpler: the soup spans [0,1]^3 so
+# the bbox is fixed by the full vertex set; give the oracle all vertices and only the selected triangles
+h = oracle.hits(v, sub_t, vs, threads=64)
+words = g.bitmask()
+idx = h[:, 0].astype(np.uint64) + np.uint64(d["dim"][0]) * (h[:, 1].astype(np.uint64) + np.uint64(d["dim"][1]) * h[:, 2].astype(np.uint64))
+assert np.all((words[(idx >> np.uint64(5)).astype(np.int64)] >> (idx & np.uint64(31)).astype(np.uint32)) & 1), "oracle hit missing in GPU bitmask"
+gsub = voxhip.Grid.voxelize(mesh, vs, voxhip.GRID_VEC, tris=None) if False else None
+log("sampled oracle subset ok: %d hits of %d triangles all present" % (len(h), len(sel)))
+# rays
+vi, pi = vx_scenes.camera_matrices(eye=(1.9, 1.3, -0.9), ctr=(0.5, 0.5, 0.5), fov_deg=40.0, aspect=10.0)
+W, H = 10000, 1000
+dt = torch.empty(W * H, dtype=torch.float32, device=dev); dp = torch.empty(W * H, dtype=torch.int32, device=dev)
+g.trace_primary_device(vi, pi, W, H, dt.data_ptr(), dp.data_ptr()); torch.cuda.synchronize()
+t0 = time.time()
+for k in range(TILES):
+    g.trace_primary_device(vi, pi, W, H, dt.data_ptr(), dp.data_ptr())
+torch.cuda.synchronize(); t1 = time.time()
+nh = int((dt > 0).sum().item())
+log("%d primary rays in %.3f s -> %.1f Mrays/s (hits per tile %d = %.1f %%)" % (TILES * W * H, t1 - t0, TILES * W * H / (t1 - t0) / 1e6, nh, 100.0 * nh / (W * H)))
+# self-consistency on a sample of hits: t == rint formula of the reported primitive's own box
+tt = dt.cpu().numpy(); pp = dp.cpu().numpy().view(np.uint32)
+hit = np.flatnonzero(tt > 0)[::max(1, len(np.flatnonzero(tt > 0)) // 200000)]
+rays = oracle.primary_rays(vi, pi, W, H)[hit]
+# box of prim p = p-th set voxel: recover voxel index through the word prefix on the host
+pc = np.cumsum(np.bitwise_count(words).astype(np.uint64)) if hasattr(np, "bitwise_count") else None
+if pc is not None:
+    wi = np.searchsorted(pc, pp[hit].astype(np.uint64), side="right")
+    before = np.where(wi > 0, pc[wi - 1], 0)
+    r = (pp[hit].astype(np.uint64) - before).astype(np.int64)
+    wv = words[wi]
+    bits = np.zeros(len(hit), np.uint64)
+    for i in range(len(hit)):  # select r-th set bit
+        x = int(wv[i]); k = int(r[i])
+        for _ in range(k): x &= x - 1
+        bits[i] = (x & -x).bit_length() - 1
+    vidx = wi.astype(np.uint64) * np.uint64(32) + bits
+    X, Y = np.uint64(d["dim"][0]), np.uint64(d["dim"][1])
+    cx, cy, cz = vidx % X, (vidx // X) % Y, vidx // (X * Y)
+    org = gi["bmin"]; half = np.float32(0.5) * vs
+    c = np.stack([org[a] + (np.stack([cx, cy, cz])[a].astype(np.float32) + np.float32(0.5)) * vs for a in range(3)], 1).astype(np.float32)
+    mn, mx = c - half, c + half
+    inv = np.float32(1.0) / rays[:, 3:]
+    tb, tp = inv * (mn - rays[:, :3]), inv * (mx - rays[:, :3])
+    t0f = np.minimum(tb, tp).max(1).astype(np.float32)
+    assert np.array_equal(t0f, tt[hit]), "t is not the rint formula of the reported primitive's box (max diff %g)" % np.abs(t0f - tt[hit]).max()
+    log("ray self-consistency ok on %d sampled hits" % len(hit))
+log("C5 done")
