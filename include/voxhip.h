@@ -165,6 +165,30 @@ vx_status vx_trace_primary_device(const vx_grid* g, const float view_inverse[16]
                                   uint32_t width, uint32_t height, float tmin, float tmax, float* dev_t,
                                   uint32_t* dev_prim /*NULL ok*/);
 
+/* Extended query: one struct for every input/output of the ray stage, including the two consumers of the hit in
+ * raytrace2.rchit: the cube-face normal (:60-73) and the shadow query (:103-122, gl_RayFlagsTerminateOnFirstHitEXT with
+ * tMax = distance to the light).  Pointers are device pointers for vx_trace_ex_device and host pointers for vx_trace_ex;
+ * every output is optional. */
+typedef struct vx_trace_args {
+    const float* rays;           /* 6 f32 per ray; NULL = primary rays from the camera below (raytrace.rgen:41-47) */
+    const float* view_inverse;   /* column-major 4x4 (host pointers in both variants) */
+    const float* proj_inverse;
+    uint32_t width, height;
+    uint64_t num_rays;           /* ignored for camera rays (= width*height) */
+    float tmin, tmax;
+    const float* tmax_per_ray;   /* optional: replaces tmax per ray */
+    int32_t any_hit;             /* 1: terminate on the first accepted hit; only `shadowed` (and t) may be requested */
+    int32_t reserved;
+    float* t;                    /* closest accepted t, -1 on miss (any_hit: some accepted t) */
+    uint32_t* prim;              /* gl_PrimitiveID of the closest hit, 0xFFFFFFFF on miss */
+    float* normal;               /* 3 f32 per ray: (+-1,0,0)/(0,+-1,0)/(0,0,+-1), zeros on miss */
+    uint8_t* shadowed;           /* 1 = an accepted hit exists */
+    vx_hit* hits;                /* device variant only: compacted hit list */
+    uint64_t* num_hits;
+} vx_trace_args;
+vx_status vx_trace_ex_device(const vx_grid* g, const vx_trace_args* args);
+vx_status vx_trace_ex(const vx_grid* g, const vx_trace_args* args);
+
 /* ---- measurement aid: per-kernel durations from HIP events recorded on the launch stream (off by default).
  * slot = 0,1,... until VX_ERR_INVALID_ARG; name is the kernel symbol as launched. */
 vx_status vx_profile_enable(int on);

@@ -70,6 +70,8 @@ def lib():
         L.vxo_hit_aabb.restype = C.c_float
         L.vxo_trace_brute.argtypes = [C.c_void_p, C.c_uint64, fp, C.c_uint64, C.c_float, C.c_float, C.c_int, fp, u32p]
         L.vxo_primary_rays.argtypes = [fp, fp, C.c_uint32, C.c_uint32, fp]
+        L.vxo_trace_any_brute.argtypes = [C.c_void_p, C.c_uint64, fp, C.c_uint64, C.c_float, C.c_float, fp, C.POINTER(C.c_uint8)]
+        L.vxo_cube_normal.argtypes = [C.c_void_p, fp, fp, C.c_float, fp]
         _lib = L
     return _lib
 
@@ -218,3 +220,27 @@ def primary_rays(view_inv, proj_inv, W, H):
     rays = np.zeros((H * W, 6), dtype=np.float32)
     lib().vxo_primary_rays(_f(vi), _f(pi), W, H, _f(rays))
     return rays
+
+
+def trace_any_brute(aabbs, rays, tmin=0.001, tmax=10000.0, tmax_per_ray=None):
+    """Shadow query (terminate on first hit): uint8[R], 1 = some box reports an accepted hit."""
+    a = np.ascontiguousarray(aabbs, dtype=AABB)
+    r = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+    out = np.zeros(r.shape[0], dtype=np.uint8)
+    tm = None if tmax_per_ray is None else np.ascontiguousarray(tmax_per_ray, dtype=np.float32)
+    lib().vxo_trace_any_brute(a.ctypes.data if a.size else None, a.size, _f(r), r.shape[0], np.float32(tmin), np.float32(tmax),
+                              _f(tm) if tm is not None else None, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out
+
+
+def cube_normals(aabbs, prim, rays, t):
+    """raytrace2.rchit:60-73 for every hit (rows of misses are zero)."""
+    a = np.ascontiguousarray(aabbs, dtype=AABB)
+    r = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+    out = np.zeros((r.shape[0], 3), dtype=np.float32)
+    tmp = np.zeros(3, dtype=np.float32)
+    for i in np.flatnonzero(np.asarray(t) > 0):
+        o = np.ascontiguousarray(r[i, :3]); d = np.ascontiguousarray(r[i, 3:])
+        lib().vxo_cube_normal(a[int(prim[i]):int(prim[i]) + 1].ctypes.data, _f(o), _f(d), np.float32(t[i]), _f(tmp))
+        out[i] = tmp
+    return out

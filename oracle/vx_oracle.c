@@ -705,3 +705,47 @@ void vxo_primary_rays(const float viewInv[16], const float projInv[16], uint32_t
             }
         }
 }
+
+/* ---------------------------------------------------------------------------------------
+ * the consumers of the hit in raytrace2.rchit.
+ *
+ * Shadow query            raytrace2.rchit:103-122: traceRayEXT with gl_RayFlagsTerminateOnFirstHitEXT | Opaque |
+ *                         SkipClosestHitShader, tMin 0.001, tMax = distance to the light; isShadowed stays true unless the
+ *                         miss shader (raytraceShadow.rmiss:25-28) runs, i.e. shadowed <=> SOME box reports an accepted hit.
+ * Cube-face normal        raytrace2.rchit:60-73.  GLSL leaves contraction of `o + d*t` to the compiler; restated without FMA.
+ * ------------------------------------------------------------------------------------- */
+void vxo_trace_any_brute(const vxo_aabb* boxes, uint64_t n, const float* rays, uint64_t nrays, float tmin, float tmax,
+                         const float* tmax_per_ray, uint8_t* shadowed)
+{
+    for (uint64_t r = 0; r < nrays; ++r) {
+        const float* o = rays + 6 * r;
+        const float* d = o + 3;
+        const float tm = tmax_per_ray ? tmax_per_ray[r] : tmax;
+        uint8_t s = 0;
+        for (uint64_t i = 0; i < n && !s; ++i) {
+            const float t = vxo_hit_aabb(&boxes[i], o, d);
+            if (t > 0.0f && t >= tmin && t <= tm) s = 1;
+        }
+        shadowed[r] = s;
+    }
+}
+
+static float sign_glsl(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+
+void vxo_cube_normal(const vxo_aabb* b, const float o[3], const float d[3], float t, float out[3])
+{
+    float v[3];
+    for (int a = 0; a < 3; ++a) {
+        const float wp = o[a] + d[a] * t;                      /* :60 */
+        const float c = (b->mn[a] + b->mx[a]) * 0.5f;          /* :65 */
+        v[a] = wp - c;
+    }
+    const float il = 1.0f / sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]); /* normalize */
+    const float nx = v[0] * il, ny = v[1] * il, nz = v[2] * il;
+    const float ax = fabsf(nx), ay = fabsf(ny), az = fabsf(nz);
+    const float maxC = fmaxf(fmaxf(ax, ay), az);               /* :70 */
+    out[0] = out[1] = out[2] = 0.0f;
+    if (maxC == ax) out[0] = sign_glsl(nx);                    /* :71-73 */
+    else if (maxC == ay) out[1] = sign_glsl(ny);
+    else out[2] = sign_glsl(nz);
+}

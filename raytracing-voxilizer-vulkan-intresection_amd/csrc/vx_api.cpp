@@ -763,20 +763,19 @@ void vx_grid_free(vx_grid* g)
 }
 
 // ---- rays -----------------------------------------------------------------------------------------------------
-static vx_status trace_common(vx_grid* g, const float* dev_rays, const vx::Camera* cam, uint64_t nrays, float tmin, float tmax, float* dev_t,
-                              uint32_t* dev_prim, vx_hit* dev_hits, uint64_t* dev_nhits)
+static vx_status trace_common(vx_grid* g, vx::TraceIO io)
 {
     VX_TRY(ensure_coarse(g));
     const uint32_t* prefix = nullptr;
     unsigned long long* idx_tmp = nullptr;
-    if (dev_prim || dev_hits) {
+    if (io.prim_out || io.hits || io.normal_out) {
         VX_TRY(ensure_prefix(g));
         prefix = g->wprefix.as<uint32_t>();
-        VX_HIP(g->idxtmp.ensure((size_t)nrays * 8 + 8));
+        VX_HIP(g->idxtmp.ensure((size_t)io.nrays * 8 + 8));
         idx_tmp = g->idxtmp.as<unsigned long long>();
-        if (!dev_t) {  // the rank / compaction pass reads t
-            VX_HIP(g->ttmp.ensure((size_t)nrays * 4 + 8));
-            dev_t = g->ttmp.as<float>();
+        if (!io.t_out) {  // the rank / normal / compaction pass reads t
+            VX_HIP(g->ttmp.ensure((size_t)io.nrays * 4 + 8));
+            io.t_out = g->ttmp.as<float>();
         }
     }
     vx::TraceMips mips;
@@ -786,8 +785,7 @@ static vx_status trace_common(vx_grid* g, const float* dev_rays, const vx::Camer
     mips.w1 = g->cwords.as<uint32_t>();
     mips.w2 = g->c2words.as<uint32_t>();
     for (int a = 0; a < 3; ++a) { mips.d1[a] = g->cdim[a]; mips.d2[a] = g->c2dim[a]; }
-    vx::launch_trace(g->g, mips, prefix, dev_rays, cam, nrays, tmin, tmax, dev_t, dev_prim, dev_hits, (unsigned long long*)dev_nhits,
-                     &g->small.as<Small>()->nhits, idx_tmp, g->stream);
+    vx::launch_trace(g->g, mips, prefix, io, &g->small.as<Small>()->nhits, idx_tmp, g->stream);
     VX_HIP(hipGetLastError());
     return VX_OK;
 }
@@ -799,7 +797,10 @@ vx_status vx_trace_device(const vx_grid* gc, const float* dev_rays, uint64_t nra
     if (dev_hits && !dev_nhits) return fail(VX_ERR_INVALID_ARG, "dev_hits needs dev_num_hits");
     vx_grid* g = const_cast<vx_grid*>(gc);
     DeviceGuard dg(g->device);
-    return trace_common(g, dev_rays, nullptr, nrays, tmin, tmax, dev_t, dev_prim, dev_hits, dev_nhits);
+    vx::TraceIO io;
+    io.rays = dev_rays; io.nrays = nrays; io.tmin = tmin; io.tmax = tmax;
+    io.t_out = dev_t; io.prim_out = dev_prim; io.hits = dev_hits; io.nhits = (unsigned long long*)dev_nhits;
+    return trace_common(g, io);
 }
 
 vx_status vx_trace_primary_device(const vx_grid* gc, const float vi[16], const float pi[16], uint32_t w, uint32_t h, float tmin, float tmax,
@@ -813,43 +814,98 @@ vx_status vx_trace_primary_device(const vx_grid* gc, const float vi[16], const f
     std::memcpy(cam.projInv, pi, 64);
     cam.width = w;
     cam.height = h;
-    return trace_common(g, nullptr, &cam, (uint64_t)w * h, tmin, tmax, dev_t, dev_prim, nullptr, nullptr);
+    vx::TraceIO io;
+    io.cam = &cam; io.nrays = (uint64_t)w * h; io.tmin = tmin; io.tmax = tmax; io.t_out = dev_t; io.prim_out = dev_prim;
+    return trace_common(g, io);
+}
+
+static vx_status args_to_io(const vx_trace_args* a, vx::Camera* cam, vx::TraceIO* io)
+{
+    if (!a) return fail(VX_ERR_INVALID_ARG, "null argument");
+    if (!a->rays && !(a->view_inverse && a->proj_inverse && a->width && a->height)) return fail(VX_ERR_INVALID_ARG, "no rays and no camera");
+    if (a->hits && !a->num_hits) return fail(VX_ERR_INVALID_ARG, "hits needs num_hits");
+    io->rays = a->rays;
+    io->nrays = a->num_rays;
+    if (!a->rays) {
+        std::memcpy(cam->viewInv, a->view_inverse, 64);
+        std::memcpy(cam->projInv, a->proj_inverse, 64);
+        cam->width = a->width;
+        cam->height = a->height;
+        io->cam = cam;
+        io->nrays = (uint64_t)a->width * a->height;
+    }
+    io->tmin = a->tmin; io->tmax = a->tmax; io->tmax_per_ray = a->tmax_per_ray; io->any_hit = a->any_hit != 0;
+    io->t_out = a->t; io->prim_out = a->prim; io->normal_out = a->normal; io->shadowed_out = a->shadowed;
+    io->hits = a->hits; io->nhits = (unsigned long long*)a->num_hits;
+    if (io->any_hit && (io->prim_out || io->normal_out || io->hits)) return fail(VX_ERR_INVALID_ARG, "any_hit reports only `shadowed` (and an arbitrary accepted t)");
+    return VX_OK;
+}
+
+vx_status vx_trace_ex_device(const vx_grid* gc, const vx_trace_args* args)
+{
+    if (!gc) return fail(VX_ERR_INVALID_ARG, "null argument");
+    vx_grid* g = const_cast<vx_grid*>(gc);
+    DeviceGuard dg(g->device);
+    vx::Camera cam{};
+    vx::TraceIO io;
+    VX_TRY(args_to_io(args, &cam, &io));
+    return trace_common(g, io);
+}
+
+// host-buffer variant: stages every non-null array through pooled device memory
+vx_status vx_trace_ex(const vx_grid* gc, const vx_trace_args* args)
+{
+    if (!gc) return fail(VX_ERR_INVALID_ARG, "null argument");
+    vx_grid* g = const_cast<vx_grid*>(gc);
+    DeviceGuard dg(g->device);
+    vx::Camera cam{};
+    vx::TraceIO io;
+    VX_TRY(args_to_io(args, &cam, &io));
+    if (args->hits) return fail(VX_ERR_UNSUPPORTED, "the compacted hit list is a device-side output: use vx_trace_ex_device");
+    const uint64_t n = io.nrays;
+    if (!n) return VX_OK;
+    DevBuf dr, dtm, dt, dp, dn, ds;
+    for (DevBuf* b : {&dr, &dtm, &dt, &dp, &dn, &ds}) b->dev = g->device;
+    auto rel = [&]() { for (DevBuf* b : {&dr, &dtm, &dt, &dp, &dn, &ds}) b->release(); };
+    hipError_t e = hipSuccess;
+    vx_status st = VX_OK;
+    if (io.rays) { e = dr.ensure((size_t)n * 24); if (e == hipSuccess) e = hipMemcpyAsync(dr.p, args->rays, (size_t)n * 24, hipMemcpyHostToDevice, g->stream); io.rays = dr.as<float>(); }
+    if (e == hipSuccess && io.tmax_per_ray) { e = dtm.ensure((size_t)n * 4); if (e == hipSuccess) e = hipMemcpyAsync(dtm.p, args->tmax_per_ray, (size_t)n * 4, hipMemcpyHostToDevice, g->stream); io.tmax_per_ray = dtm.as<float>(); }
+    if (e == hipSuccess && args->t) { e = dt.ensure((size_t)n * 4); io.t_out = dt.as<float>(); }
+    if (e == hipSuccess && args->prim) { e = dp.ensure((size_t)n * 4); io.prim_out = dp.as<uint32_t>(); }
+    if (e == hipSuccess && args->normal) { e = dn.ensure((size_t)n * 12); io.normal_out = dn.as<float>(); }
+    if (e == hipSuccess && args->shadowed) { e = ds.ensure((size_t)n); io.shadowed_out = ds.as<uint8_t>(); }
+    if (e == hipSuccess) st = trace_common(g, io);
+    if (e == hipSuccess && st == VX_OK) {
+        if (args->t) e = hipMemcpyAsync(args->t, dt.p, (size_t)n * 4, hipMemcpyDeviceToHost, g->stream);
+        if (e == hipSuccess && args->prim) e = hipMemcpyAsync(args->prim, dp.p, (size_t)n * 4, hipMemcpyDeviceToHost, g->stream);
+        if (e == hipSuccess && args->normal) e = hipMemcpyAsync(args->normal, dn.p, (size_t)n * 12, hipMemcpyDeviceToHost, g->stream);
+        if (e == hipSuccess && args->shadowed) e = hipMemcpyAsync(args->shadowed, ds.p, (size_t)n, hipMemcpyDeviceToHost, g->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+    }
+    rel();
+    if (st != VX_OK) return st;
+    VX_HIP(e);
+    return VX_OK;
 }
 
 vx_status vx_trace(const vx_grid* gc, const float* host_rays, uint64_t nrays, float tmin, float tmax, float* host_t, uint32_t* host_prim,
                    uint64_t* num_hits)
 {
     if (!gc || (nrays && !host_rays)) return fail(VX_ERR_INVALID_ARG, "null argument");
-    vx_grid* g = const_cast<vx_grid*>(gc);
-    DeviceGuard dg(g->device);
     if (num_hits) *num_hits = 0;
     if (!nrays) return VX_OK;
-    DevBuf dr, dt, dp;
-    dr.dev = dt.dev = dp.dev = g->device;
-    vx_status st = VX_OK;
-    hipError_t e = dr.ensure((size_t)nrays * 24);
-    if (e == hipSuccess) e = dt.ensure((size_t)nrays * 4);
-    if (e == hipSuccess && host_prim) e = dp.ensure((size_t)nrays * 4);
-    if (e == hipSuccess) e = hipMemcpyAsync(dr.p, host_rays, (size_t)nrays * 24, hipMemcpyHostToDevice, g->stream);
-    if (e == hipSuccess) {
-        st = trace_common(g, dr.as<float>(), nullptr, nrays, tmin, tmax, dt.as<float>(), host_prim ? dp.as<uint32_t>() : nullptr, nullptr, nullptr);
-        if (st == VX_OK) {
-            std::vector<float> tbuf;
-            float* tdst = host_t;
-            if (!tdst) { tbuf.resize(nrays); tdst = tbuf.data(); }
-            e = hipMemcpyAsync(tdst, dt.p, (size_t)nrays * 4, hipMemcpyDeviceToHost, g->stream);
-            if (e == hipSuccess && host_prim) e = hipMemcpyAsync(host_prim, dp.p, (size_t)nrays * 4, hipMemcpyDeviceToHost, g->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
-            if (e == hipSuccess && num_hits) {
-                uint64_t n = 0;
-                for (uint64_t i = 0; i < nrays; ++i) n += tdst[i] > 0.0f;
-                *num_hits = n;
-            }
-        }
+    std::vector<float> tbuf;
+    float* tdst = host_t;
+    if (!tdst) { tbuf.resize(nrays); tdst = tbuf.data(); }
+    vx_trace_args a{};
+    a.rays = host_rays; a.num_rays = nrays; a.tmin = tmin; a.tmax = tmax; a.t = tdst; a.prim = host_prim;
+    VX_TRY(vx_trace_ex(gc, &a));
+    if (num_hits) {
+        uint64_t n = 0;
+        for (uint64_t i = 0; i < nrays; ++i) n += tdst[i] > 0.0f;
+        *num_hits = n;
     }
-    dr.release(); dt.release(); dp.release();
-    if (st != VX_OK) return st;
-    VX_HIP(e);
     return VX_OK;
 }
 

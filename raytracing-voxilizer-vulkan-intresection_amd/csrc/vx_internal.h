@@ -85,9 +85,22 @@ struct TraceMips {
     uint32_t d1[3];
     uint32_t d2[3];
 };
-void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* word_prefix, const float* rays, const Camera* cam,
-                  uint64_t nrays, float tmin, float tmax, float* t_out, uint32_t* prim_out, vx_hit* hits, unsigned long long* nhits,
-                  unsigned long long* next_ray /*device work counter*/, unsigned long long* idx_tmp /*nrays x 8 B when prim/hits wanted*/,
+struct TraceIO {
+    const float* rays = nullptr;         // 6 f32 per ray, or null with cam
+    const Camera* cam = nullptr;         // primary rays generated in-kernel
+    uint64_t nrays = 0;
+    float tmin = 0.001f, tmax = 10000.0f;
+    const float* tmax_per_ray = nullptr; // optional per-ray tMax
+    bool any_hit = false;                // terminate on the first accepted hit (shadow query)
+    float* t_out = nullptr;
+    uint32_t* prim_out = nullptr;
+    float* normal_out = nullptr;         // 3 f32 per ray: cube-face normal (zero for misses)
+    uint8_t* shadowed_out = nullptr;     // 1 = some accepted hit
+    vx_hit* hits = nullptr;
+    unsigned long long* nhits = nullptr;
+};
+void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* word_prefix, const TraceIO& io,
+                  unsigned long long* next_ray /*device work counter*/, unsigned long long* idx_tmp /*nrays x 8 B when ranks are wanted*/,
                   hipStream_t s);
 
 // single-voxel helpers

@@ -145,6 +145,7 @@ struct Lane {
     float t_in;                                // entry time of the current cell
     int lvl;
     float tolp;                                // position tolerance of this ray
+    float tmax;                                // this ray's tMax (shadow rays: distance to the light)
     float tau_term;                            // termination margin: 2 x the tolerance of the ray's major axis
     // visit protocol of the current cell: cells still to look at (bit j = jx + 3*jy + 9*jz, 0 stay / 1 forward / 2 backward)
     uint32_t todo;
@@ -194,6 +195,33 @@ __device__ __forceinline__ void enter_level(Lane& R, const GridParams& g, float 
     R.t_in = t_lo;
     R.emask = 0;
     R.tau_ent = 0.0f;
+}
+
+// Ray r of the batch: from the ray buffer, or generated from the reference camera model (raytrace.rgen:41-47; mat*vec in glm's
+// association (m0*v0 + m1*v1) + (m2*v2 + m3*v3)).
+template <bool PRIMARY>
+__device__ __forceinline__ void load_ray(uint64_t r, const float* __restrict__ rays, const Camera& cam, float& ox, float& oy, float& oz, float& dx,
+                                         float& dy, float& dz)
+{
+    if (PRIMARY) {
+        const uint32_t px = (uint32_t)(r % cam.width), py = (uint32_t)(r / cam.width);
+        const float u = ((float)px + 0.5f) / (float)cam.width, v = ((float)py + 0.5f) / (float)cam.height;
+        const float ndx = u * 2.0f - 1.0f, ndy = v * 2.0f - 1.0f;
+        float tg[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            tg[k] = (cam.projInv[0 + k] * ndx + cam.projInv[4 + k] * ndy) + (cam.projInv[8 + k] * 1.0f + cam.projInv[12 + k] * 1.0f);
+        const float il = 1.0f / sqrtf((tg[0] * tg[0] + tg[1] * tg[1]) + tg[2] * tg[2]);
+        const float n0 = tg[0] * il, n1 = tg[1] * il, n2 = tg[2] * il;
+        ox = cam.viewInv[12]; oy = cam.viewInv[13]; oz = cam.viewInv[14];
+        dx = (cam.viewInv[0] * n0 + cam.viewInv[4] * n1) + cam.viewInv[8] * n2;
+        dy = (cam.viewInv[1] * n0 + cam.viewInv[5] * n1) + cam.viewInv[9] * n2;
+        dz = (cam.viewInv[2] * n0 + cam.viewInv[6] * n1) + cam.viewInv[10] * n2;
+    } else {
+        const float2* rp = reinterpret_cast<const float2*>(rays + 6 * r);
+        const float2 a = rp[0], b = rp[1], c = rp[2];
+        ox = a.x; oy = a.y; oz = b.x; dx = b.y; dy = c.x; dz = c.y;
+    }
 }
 
 // Ray set-up: tolerances, grid clip, top-level start.  Returns false when the ray cannot touch the grid.
@@ -462,9 +490,10 @@ __device__ __forceinline__ bool upper_step(Lane& R, const GridParams& g, const T
 
 // Persistent waves with dynamic ray fetch.  Exit condition every wave reaches: the counter passes nrays (no refill
 // possible) and every lane's ray has finished; each ray finishes in a bounded number of steps.
-template <bool PRIMARY, bool LDS_M1>
+template <bool PRIMARY, bool LDS_M1, bool ANYHIT>
 __global__ __launch_bounds__(256) void k_trace(GridParams g, TraceMips M, const float* __restrict__ rays, Camera cam, uint64_t nrays, float tmin,
-                                               float tmax, float* __restrict__ t_out, unsigned long long* __restrict__ idx_out,
+                                               float tmax, const float* __restrict__ tmax_per_ray, float* __restrict__ t_out, unsigned long long* __restrict__ idx_out,
+                                               uint8_t* __restrict__ shadowed_out,
                                                unsigned long long* next_ray, uint32_t m1_words, int kStepsPerRound, int kRefillBelow,
                                                int kItersPerRound, int kChunkRays)
 {
@@ -515,27 +544,10 @@ __global__ __launch_bounds__(256) void k_trace(GridParams g, TraceMips M, const 
                 const uint64_t mine = pos < take ? first + pos : (take < need ? second + (pos - take) : nrays);
                 if (mine < nrays) {
                     r = mine;
-                    if (PRIMARY) {
-                        // raytrace.rgen:41-47; mat*vec in glm's association (m0*v0 + m1*v1) + (m2*v2 + m3*v3)
-                        const uint32_t px = (uint32_t)(r % cam.width), py = (uint32_t)(r / cam.width);
-                        const float u = ((float)px + 0.5f) / (float)cam.width, v = ((float)py + 0.5f) / (float)cam.height;
-                        const float ndx = u * 2.0f - 1.0f, ndy = v * 2.0f - 1.0f;
-                        float tg[3];
-#pragma unroll
-                        for (int k = 0; k < 3; ++k)
-                            tg[k] = (cam.projInv[0 + k] * ndx + cam.projInv[4 + k] * ndy) + (cam.projInv[8 + k] * 1.0f + cam.projInv[12 + k] * 1.0f);
-                        const float il = 1.0f / sqrtf((tg[0] * tg[0] + tg[1] * tg[1]) + tg[2] * tg[2]);
-                        const float n0 = tg[0] * il, n1 = tg[1] * il, n2 = tg[2] * il;
-                        R.ox = cam.viewInv[12]; R.oy = cam.viewInv[13]; R.oz = cam.viewInv[14];
-                        R.dx = (cam.viewInv[0] * n0 + cam.viewInv[4] * n1) + cam.viewInv[8] * n2;
-                        R.dy = (cam.viewInv[1] * n0 + cam.viewInv[5] * n1) + cam.viewInv[9] * n2;
-                        R.dz = (cam.viewInv[2] * n0 + cam.viewInv[6] * n1) + cam.viewInv[10] * n2;
-                    } else {
-                        const float2* rp = reinterpret_cast<const float2*>(rays + 6 * r);
-                        const float2 a = rp[0], b = rp[1], c = rp[2];
-                        R.ox = a.x; R.oy = a.y; R.oz = b.x; R.dx = b.y; R.dy = c.x; R.dz = c.y;
-                    }
-                    busy = setup_ray(R, g, M, inv_vs, tmax);
+                    load_ray<PRIMARY>(r, rays, cam, R.ox, R.oy, R.oz, R.dx, R.dy, R.dz);
+                    const float tmax_r = tmax_per_ray ? tmax_per_ray[r] : tmax;
+                    R.tmax = tmax_r;
+                    busy = setup_ray(R, g, M, inv_vs, tmax_r);
 #ifdef VX_TRACE_DEBUG_CYCLES
                     dbg_t0 = wall_clock64();
 #endif
@@ -543,6 +555,7 @@ __global__ __launch_bounds__(256) void k_trace(GridParams g, TraceMips M, const 
                     if (!busy) {  // cannot touch the grid: retire at once as a miss
                         if (t_out) t_out[r] = -1.0f;
                         if (idx_out) idx_out[r] = ~0ull;
+                        if (shadowed_out) shadowed_out[r] = 0;
                         r = ~0ull;
                     }
                 }
@@ -567,8 +580,10 @@ __global__ __launch_bounds__(256) void k_trace(GridParams g, TraceMips M, const 
             const bool pend = busy && R.pending;
             if (!__ballot(pend)) break;  // every live lane finished its ray in this round
             if (pend) {
-                brick_test(R, g, M, inv_vs, R.tolp, R.bx, R.by, R.bz, tmin, tmax);
+                brick_test(R, g, M, inv_vs, R.tolp, R.bx, R.by, R.bz, tmin, R.tmax);
                 R.pending = false;
+                // shadow query (gl_RayFlagsTerminateOnFirstHitEXT, raytrace2.rchit:108): any accepted hit ends the ray
+                if (ANYHIT && R.best_idx != ~0ull) finished = true;
             }
         }
         // ---- retire: t and the voxel index of the hit; the primitive rank (two dependent loads) and the hit compaction are
@@ -583,16 +598,20 @@ __global__ __launch_bounds__(256) void k_trace(GridParams g, TraceMips M, const 
 #endif
             if (t_out) t_out[r] = best_t;
             if (idx_out) idx_out[r] = R.best_idx;
+            if (shadowed_out) shadowed_out[r] = R.best_idx != ~0ull ? 1 : 0;
             busy = false;
             r = ~0ull;
         }
     }
 }
 
-// Primitive id (== gl_PrimitiveID: rank of the voxel in the ascending AABB list) and wavefront hit compaction.
-__global__ __launch_bounds__(256) void k_rank(const float* __restrict__ t, const unsigned long long* __restrict__ idx, uint64_t nrays,
-                                              const uint32_t* __restrict__ words, const uint32_t* __restrict__ word_prefix,
-                                              uint32_t* __restrict__ prim_out, vx_hit* __restrict__ hits, unsigned long long* nhits)
+// Per-ray post-pass over all rays: primitive id (== gl_PrimitiveID: rank of the voxel in the ascending AABB list), the
+// cube-face normal of raytrace2.rchit:60-73, and wavefront hit compaction.
+template <bool PRIMARY>
+__global__ __launch_bounds__(256) void k_rank(const float* __restrict__ t, const unsigned long long* __restrict__ idx, uint64_t nrays, GridParams g,
+                                              const uint32_t* __restrict__ words, const uint32_t* __restrict__ word_prefix, const float* __restrict__ rays,
+                                              Camera cam, uint32_t* __restrict__ prim_out, float* __restrict__ normal_out, vx_hit* __restrict__ hits,
+                                              unsigned long long* nhits)
 {
     const uint64_t r = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     const bool active = r < nrays;
@@ -601,12 +620,34 @@ __global__ __launch_bounds__(256) void k_rank(const float* __restrict__ t, const
     if (active) {
         tt = t[r];
         const unsigned long long i = idx[r];
+        float n0 = 0.0f, n1 = 0.0f, n2 = 0.0f;
         if (i != ~0ull) {
             const uint64_t wi = i >> 5;
             const uint32_t bit = (uint32_t)i & 31u;
             prim = word_prefix[wi] + __popc(words[wi] & ((1u << bit) - 1u));
+            if (normal_out) {
+                const uint64_t XY = (uint64_t)g.dim[0] * g.dim[1];
+                const uint32_t z = (uint32_t)(i / XY);
+                const uint32_t rem = (uint32_t)(i - (uint64_t)z * XY);
+                const uint32_t y = rem / g.dim[0], x = rem - y * g.dim[0];
+                float bb[6], ox, oy, oz, dx, dy, dz;
+                cell_aabb(g, x, y, z, bb);
+                load_ray<PRIMARY>(r, rays, cam, ox, oy, oz, dx, dy, dz);
+                // worldPos = origin + direction * t; worldNrm = normalize(worldPos - (min + max) * 0.5)      rchit:60-65
+                const float vx_ = (ox + dx * tt) - ((bb[0] + bb[3]) * 0.5f);
+                const float vy_ = (oy + dy * tt) - ((bb[1] + bb[4]) * 0.5f);
+                const float vz_ = (oz + dz * tt) - ((bb[2] + bb[5]) * 0.5f);
+                const float il = 1.0f / sqrtf((vx_ * vx_ + vy_ * vy_) + vz_ * vz_);
+                const float nx = vx_ * il, ny = vy_ * il, nz = vz_ * il;
+                const float ax = fabsf(nx), ay = fabsf(ny), az = fabsf(nz);
+                const float maxC = fmaxf(fmaxf(ax, ay), az);                                                // rchit:70
+                if (maxC == ax) n0 = nx > 0.0f ? 1.0f : (nx < 0.0f ? -1.0f : 0.0f);                         // rchit:71-73
+                else if (maxC == ay) n1 = ny > 0.0f ? 1.0f : (ny < 0.0f ? -1.0f : 0.0f);
+                else n2 = nz > 0.0f ? 1.0f : (nz < 0.0f ? -1.0f : 0.0f);
+            }
         }
         if (prim_out) prim_out[r] = prim;
+        if (normal_out) { normal_out[3 * r] = n0; normal_out[3 * r + 1] = n1; normal_out[3 * r + 2] = n2; }
     }
     if (hits) {
         const bool hit = active && prim != 0xFFFFFFFFu;
@@ -625,14 +666,14 @@ __global__ __launch_bounds__(256) void k_rank(const float* __restrict__ t, const
     }
 }
 
-void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* word_prefix, const float* rays, const Camera* cam, uint64_t nrays,
-                  float tmin, float tmax, float* t_out, uint32_t* prim_out, vx_hit* hits, unsigned long long* nhits, unsigned long long* next_ray,
+void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* word_prefix, const TraceIO& io, unsigned long long* next_ray,
                   unsigned long long* idx_tmp, hipStream_t s)
 {
+    const uint64_t nrays = io.nrays;
     if (!nrays) return;
     (void)hipMemsetAsync(next_ray, 0, sizeof(unsigned long long), s);
     Camera c{};
-    if (cam) c = *cam;
+    if (io.cam) c = *io.cam;
     const uint64_t n1 = (uint64_t)mips.d1[0] * mips.d1[1] * mips.d1[2];
     const uint32_t m1_words = (uint32_t)((n1 + 31) / 32);
     const bool lds_m1 = (size_t)m1_words * 4 <= 40960;  // 4 workgroups x 40 KiB fit the CU's 160 KiB
@@ -645,17 +686,22 @@ void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* wo
     uint64_t nblk = (nrays + 255) / 256;
     if (nblk > (uint64_t)env_blocks) nblk = (uint64_t)env_blocks;
     const dim3 grid((unsigned)nblk), block(256);
-    const bool want_rank = (prim_out || hits) && word_prefix && idx_tmp;
+    const bool want_rank = (io.prim_out || io.hits || io.normal_out) && word_prefix && idx_tmp && io.t_out;
     unsigned long long* idx_out = want_rank ? idx_tmp : nullptr;
     const size_t shmem = lds_m1 ? (size_t)m1_words * 4 : 0;
-#define VX_LAUNCH(P, L) \
-    VX_KL((k_trace<P, L>), grid, block, shmem, s, g, mips, rays, c, nrays, tmin, tmax, t_out, idx_out, next_ray, m1_words, env_steps, env_refill, env_iters, env_chunk)
-    if (cam) { if (lds_m1) VX_LAUNCH(true, true); else VX_LAUNCH(true, false); }
-    else { if (lds_m1) VX_LAUNCH(false, true); else VX_LAUNCH(false, false); }
+#define VX_LAUNCH(P, L, A)                                                                                                                        \
+    VX_KL((k_trace<P, L, A>), grid, block, shmem, s, g, mips, io.rays, c, nrays, io.tmin, io.tmax, io.tmax_per_ray, io.t_out, idx_out, io.shadowed_out, \
+          next_ray, m1_words, env_steps, env_refill, env_iters, env_chunk)
+#define VX_LAUNCH2(P, L) do { if (io.any_hit) VX_LAUNCH(P, L, true); else VX_LAUNCH(P, L, false); } while (0)
+    if (io.cam) { if (lds_m1) VX_LAUNCH2(true, true); else VX_LAUNCH2(true, false); }
+    else { if (lds_m1) VX_LAUNCH2(false, true); else VX_LAUNCH2(false, false); }
+#undef VX_LAUNCH2
 #undef VX_LAUNCH
     if (want_rank) {
-        if (hits && nhits) (void)hipMemsetAsync(nhits, 0, sizeof(unsigned long long), s);
-        VX_KL(k_rank, dim3((unsigned)((nrays + 255) / 256)), block, 0, s, t_out, idx_tmp, nrays, mips.w0, word_prefix, prim_out, hits, nhits);
+        if (io.hits && io.nhits) (void)hipMemsetAsync(io.nhits, 0, sizeof(unsigned long long), s);
+        const dim3 rgrid((unsigned)((nrays + 255) / 256));
+        if (io.cam) VX_KL(k_rank<true>, rgrid, block, 0, s, io.t_out, idx_tmp, nrays, g, mips.w0, word_prefix, io.rays, c, io.prim_out, io.normal_out, io.hits, io.nhits);
+        else VX_KL(k_rank<false>, rgrid, block, 0, s, io.t_out, idx_tmp, nrays, g, mips.w0, word_prefix, io.rays, c, io.prim_out, io.normal_out, io.hits, io.nhits);
     }
 }
 

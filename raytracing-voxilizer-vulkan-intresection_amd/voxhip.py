@@ -32,6 +32,13 @@ class VoxelizeOpts(C.Structure):
                 ("tri_begin", C.c_uint64), ("tri_end", C.c_uint64), ("stream", C.c_void_p)]
 
 
+class TraceArgs(C.Structure):
+    _fields_ = [("rays", C.c_void_p), ("view_inverse", C.POINTER(C.c_float)), ("proj_inverse", C.POINTER(C.c_float)), ("width", C.c_uint32),
+                ("height", C.c_uint32), ("num_rays", C.c_uint64), ("tmin", C.c_float), ("tmax", C.c_float), ("tmax_per_ray", C.c_void_p),
+                ("any_hit", C.c_int32), ("reserved", C.c_int32), ("t", C.c_void_p), ("prim", C.c_void_p), ("normal", C.c_void_p),
+                ("shadowed", C.c_void_p), ("hits", C.c_void_p), ("num_hits", C.c_void_p)]
+
+
 class VxError(RuntimeError):
     def __init__(self, status, msg):
         super().__init__("%s: %s" % (STATUS_NAMES.get(status, status), msg))
@@ -50,7 +57,7 @@ SYMBOLS = [
     "vx_grid_aabbs_device", "vx_grid_free",
     "vx_octree_build", "vx_octree_num_items", "vx_octree_num_nodes", "vx_octree_bytes", "vx_octree_items", "vx_octree_nodes",
     "vx_octree_root_bounds", "vx_octree_aabbs", "vx_octree_aabbs_device", "vx_octree_free",
-    "vx_trace", "vx_trace_device", "vx_trace_primary_device",
+    "vx_trace", "vx_trace_device", "vx_trace_primary_device", "vx_trace_ex", "vx_trace_ex_device",
     "vx_profile_enable", "vx_profile_reset", "vx_profile_read",
     "vx_shard_words", "vx_shard_range",
 ]
@@ -145,6 +152,8 @@ def lib():
     L.vx_trace_primary_device.argtypes = [vp, fp, fp, C.c_uint32, C.c_uint32, C.c_float, C.c_float, vp, vp]
     L.vx_profile_enable.argtypes = [C.c_int]
     L.vx_profile_read.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), u64p]
+    L.vx_trace_ex.argtypes = [vp, C.POINTER(TraceArgs)]
+    L.vx_trace_ex_device.argtypes = [vp, C.POINTER(TraceArgs)]
     L.vx_shard_words.argtypes = [C.c_uint64, C.c_int, C.c_int, u64p, u64p, u64p]
     L.vx_shard_words.restype = None
     L.vx_shard_range.argtypes = [C.c_uint64, C.c_int, C.c_int, u64p, u64p]
@@ -349,6 +358,37 @@ class Grid:
         _check(lib().vx_trace(self.h, r.ctypes.data, r.shape[0], np.float32(tmin), np.float32(tmax), t.ctypes.data,
                               p.ctypes.data if want_prim else None, C.byref(nh)))
         return (t, p, nh.value) if want_prim else (t, nh.value)
+
+    def trace_ex(self, rays=None, camera=None, tmin=0.001, tmax=10000.0, tmax_per_ray=None, any_hit=False, want=("t", "prim")):
+        """Host-buffer extended query -> dict of the requested outputs (t, prim, normal, shadowed)."""
+        a = TraceArgs()
+        keep = []
+        if rays is not None:
+            r = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+            keep.append(r)
+            a.rays, a.num_rays, n = r.ctypes.data, r.shape[0], r.shape[0]
+        else:
+            vi, pi, w, h = camera
+            cvi = (C.c_float * 16)(*[float(x) for x in np.asarray(vi).reshape(16)])
+            cpi = (C.c_float * 16)(*[float(x) for x in np.asarray(pi).reshape(16)])
+            keep += [cvi, cpi]
+            a.view_inverse, a.proj_inverse, a.width, a.height, n = cvi, cpi, w, h, w * h
+        a.tmin, a.tmax, a.any_hit = np.float32(tmin), np.float32(tmax), 1 if any_hit else 0
+        if tmax_per_ray is not None:
+            tm = np.ascontiguousarray(tmax_per_ray, dtype=np.float32)
+            keep.append(tm)
+            a.tmax_per_ray = tm.ctypes.data
+        out = {}
+        if "t" in want:
+            out["t"] = np.zeros(n, np.float32); a.t = out["t"].ctypes.data
+        if "prim" in want:
+            out["prim"] = np.zeros(n, np.uint32); a.prim = out["prim"].ctypes.data
+        if "normal" in want:
+            out["normal"] = np.zeros((n, 3), np.float32); a.normal = out["normal"].ctypes.data
+        if "shadowed" in want:
+            out["shadowed"] = np.zeros(n, np.uint8); a.shadowed = out["shadowed"].ctypes.data
+        _check(lib().vx_trace_ex(self.h, C.byref(a)))
+        return out
 
     def trace_device(self, rays_ptr, nrays, t_ptr, prim_ptr=None, hits_ptr=None, nhits_ptr=None, tmin=0.001, tmax=10000.0):
         _check(lib().vx_trace_device(self.h, rays_ptr, nrays, np.float32(tmin), np.float32(tmax), t_ptr, prim_ptr, hits_ptr, nhits_ptr))

@@ -404,3 +404,54 @@ def test_soup_200k_at_512(gpu):
     o = gpu.Octree(mesh, vs)
     r = oracle.octree(v, t, vs, threads=16)
     assert np.array_equal(o.items(), r["items"]) and o.nodes().tobytes() == r["nodes"].tobytes()
+
+
+# ---------------------------------------------------------------------------------------------- raytrace2.rchit consumers
+@pytest.mark.parametrize("name,vs", [("rotcube", 0.09), ("adversarial", 0.0625), ("blob70k", 2.0 / 64)])
+def test_shadow_query_and_normals(gpu, name, vs):
+    """Shadow rays (terminate on first hit, per-ray tMax = distance to the light; raytrace2.rchit:103-122) and the cube-face
+    normal (rchit:60-73) against the oracle's restatements."""
+    v, t = vx_scenes.scene(name)
+    vs = np.float32(vs)
+    g = gpu.Grid.voxelize(gpu.Mesh.from_arrays(v, t), vs)
+    ow, _, gi = oracle.build_bool(v, t, vs)
+    oa = oracle.bool_aabbs(ow, gi, vs)
+    n = 6000
+    hi = gi["bmin"] + np.array(gi["dim"], np.float32) * vs
+    rays = np.concatenate([vx_scenes.random_rays(n, gi["bmin"], hi, seed=21), corner_rays(gi, float(vs), n, 22), inside_rays(gi, float(vs), n, 23)])
+    # closest hit + normal
+    out = g.trace_ex(rays, want=("t", "prim", "normal"))
+    ot, op = oracle.trace_brute(oa, rays)
+    assert np.array_equal(out["t"], ot) and np.array_equal(out["prim"], op)
+    on = oracle.cube_normals(oa, op, rays, ot)
+    assert np.array_equal(out["normal"], on)
+    hitrows = ot > 0
+    assert np.all(np.abs(out["normal"][hitrows]).sum(1) == 1.0) and not out["normal"][~hitrows].any()
+    # shadow query with a scalar and with a per-ray tMax
+    sh = g.trace_ex(rays, any_hit=True, want=("shadowed",))["shadowed"]
+    assert np.array_equal(sh, oracle.trace_any_brute(oa, rays))
+    assert np.array_equal(sh.astype(bool), ot > 0)                     # same interval: shadowed <=> a closest hit exists
+    rng = np.random.default_rng(24)
+    tm = np.where(ot > 0, ot * rng.choice([0.5, 0.999, 1.0, 1.001, 2.0], size=len(ot)).astype(np.float32), np.float32(50.0)).astype(np.float32)
+    sh2 = g.trace_ex(rays, any_hit=True, tmax_per_ray=tm, want=("shadowed",))["shadowed"]
+    assert np.array_equal(sh2, oracle.trace_any_brute(oa, rays, tmax_per_ray=tm))
+    # per-ray tMax also applies to the closest-hit query
+    t3 = g.trace_ex(rays, tmax_per_ray=tm, want=("t",))["t"]
+    exp = np.array([oracle.trace_brute(oa, rays[i:i + 1], tmax=float(tm[i]))[0][0] for i in range(0, len(rays), 37)], np.float32)
+    assert np.array_equal(t3[::37], exp)
+
+
+def test_primary_rays_with_normals(gpu):
+    v, t = vx_scenes.rotated_cube(half=1.0, offset=(0.0, 1.0, 0.0))
+    vs = np.float32(0.05)
+    g = gpu.Grid.voxelize(gpu.Mesh.from_arrays(v, t), vs)
+    ow, _, gi = oracle.build_bool(v, t, vs)
+    oa = oracle.bool_aabbs(ow, gi, vs)
+    vi, pi = vx_scenes.camera_matrices()
+    W, H = 160, 90
+    out = g.trace_ex(camera=(vi, pi, W, H), want=("t", "prim", "normal"))
+    rays = oracle.primary_rays(vi, pi, W, H)
+    ref = g.trace_ex(rays, want=("t", "prim", "normal"))
+    assert np.array_equal(out["t"] > 0, ref["t"] > 0) and np.allclose(out["t"], ref["t"], rtol=0, atol=1e-5)
+    same = out["prim"] == ref["prim"]
+    assert same.mean() > 0.999 and np.array_equal(out["normal"][same], ref["normal"][same])
