@@ -8,7 +8,13 @@
 //   --rays WxH                          also trace WxH primary rays from the reference camera (main.cpp:92, rgen:41-51)
 //   --dump FILE                         write the AABB list as raw 24-byte records
 //   --bench RUNS                        Benchmaker<T>{path, vs, RUNS} printout (hello_vulkan.h:172-241)
+//   --render FILE.ppm [--size WxH]      the reference's picture of the voxels without Vulkan: primary rays from the reference
+//                                       camera (main.cpp:92, raytrace.rgen:41-51), cube normals + Lambert + shadow ray as in
+//                                       raytrace2.rchit:53-137 with the default material and light (hello_vulkan.h:84-90), miss
+//                                       colour raytrace.rmiss:37, gamma post.frag:36.  Rays run on the GPU, the per-pixel shading
+//                                       arithmetic (display, not the hot path) on the host.
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -28,8 +34,92 @@ void dump(const std::string& file, const std::vector<Aabb>& a)
     f.write(reinterpret_cast<const char*>(a.data()), (std::streamsize)(a.size() * sizeof(Aabb)));
 }
 
+struct V3 { float x, y, z; };
+inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline V3 norm(V3 a) { const float l = std::sqrt(dot(a, a)); return {a.x / l, a.y / l, a.z / l}; }
+
+// viewInverse / projInverse as the reference uploads them (hello_vulkan.cpp:69-77): lookAt RH, perspectiveRH_ZO, [1][1] *= -1
+void camera(float vi[16], float pi[16], float aspect)
+{
+    const V3 eye{6.16636f, 2.42256f, -3.15471f}, ctr{0.f, 1.f, 0.f}, up{0.f, 1.f, 0.f};  // main.cpp:92
+    const V3 f = norm(ctr - eye), s = norm(cross(f, up)), u = cross(s, f);
+    const float m[16] = {s.x, s.y, s.z, 0, u.x, u.y, u.z, 0, -f.x, -f.y, -f.z, 0, eye.x, eye.y, eye.z, 1};  // columns: s, u, -f, eye
+    for (int i = 0; i < 16; ++i) vi[i] = m[i];
+    const float fov = 60.0f * 3.14159265358979f / 180.0f;  // nvpro CameraManip default (third-party; unpinned in the tree)
+    const float t = std::tan(fov * 0.5f), zn = 0.1f, zf = 1000.0f;
+    const float a = 1.0f / (aspect * t), b = -1.0f / t, c = zf / (zn - zf), d = -(zf * zn) / (zf - zn);
+    for (int i = 0; i < 16; ++i) pi[i] = 0.f;
+    pi[0] = 1.0f / a; pi[5] = 1.0f / b; pi[11] = 1.0f / d; pi[14] = -1.0f; pi[15] = c / d;  // column-major inverse of the projection
+}
+
+int render(vx_grid* grid, const std::string& file, uint32_t W, uint32_t H)
+{
+    float vi[16], pi[16];
+    camera(vi, pi, (float)W / (float)H);
+    const size_t n = (size_t)W * H;
+    std::vector<float> t(n), nrm(3 * n), rays(6 * n), tmaxs(n);
+    std::vector<uint32_t> prim(n);
+    std::vector<uint8_t> shadowed(n);
+    vx_trace_args a{};
+    a.view_inverse = vi; a.proj_inverse = pi; a.width = W; a.height = H; a.tmin = 0.001f; a.tmax = 10000.0f;  // rgen:50-51
+    a.t = t.data(); a.prim = prim.data(); a.normal = nrm.data();
+    vxdetail::check(vx_trace_ex(grid, &a));
+    // shadow rays from the hit points toward the point light (rchit:76-122)
+    const V3 light{10.f, 55.f, 8.f};  // hello_vulkan.h:86
+    const float intensity = 1000.f;   // :88
+    const V3 org{vi[12], vi[13], vi[14]};
+    std::vector<V3> dirs(n);
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t px = (uint32_t)(i % W), py = (uint32_t)(i / W);
+        const float u = ((float)px + 0.5f) / (float)W, v = ((float)py + 0.5f) / (float)H, dx = u * 2.f - 1.f, dy = v * 2.f - 1.f;
+        const V3 tg = norm(V3{pi[0] * dx + pi[4] * dy + pi[8] + pi[12], pi[1] * dx + pi[5] * dy + pi[9] + pi[13], pi[2] * dx + pi[6] * dy + pi[10] + pi[14]});
+        dirs[i] = V3{vi[0] * tg.x + vi[4] * tg.y + vi[8] * tg.z, vi[1] * tg.x + vi[5] * tg.y + vi[9] * tg.z, vi[2] * tg.x + vi[6] * tg.y + vi[10] * tg.z};
+        const V3 wp = org + dirs[i] * (t[i] > 0 ? t[i] : 0.f);
+        const V3 l = light - wp;
+        const float dist = std::sqrt(dot(l, l));
+        const V3 L = l * (1.0f / dist);
+        rays[6 * i + 0] = wp.x; rays[6 * i + 1] = wp.y; rays[6 * i + 2] = wp.z;
+        rays[6 * i + 3] = L.x == 0.f ? 1e-20f : L.x; rays[6 * i + 4] = L.y == 0.f ? 1e-20f : L.y; rays[6 * i + 5] = L.z == 0.f ? 1e-20f : L.z;
+        tmaxs[i] = dist;
+    }
+    vx_trace_args sa{};
+    sa.rays = rays.data(); sa.num_rays = n; sa.tmin = 0.001f; sa.tmax = 10000.0f; sa.tmax_per_ray = tmaxs.data(); sa.any_hit = 1;
+    sa.shadowed = shadowed.data();
+    vxdetail::check(vx_trace_ex(grid, &sa));
+    const MaterialObj mat{};  // the single default material createAABB uploads (hello_vulkan.cpp:701-702)
+    std::vector<unsigned char> img(3 * n);
+    size_t hits = 0;
+    for (size_t i = 0; i < n; ++i) {
+        float c[3] = {0.8f, 0.8f, 0.8f};  // rmiss:37 with the white clear colour of main.cpp:184
+        if (t[i] > 0) {
+            ++hits;
+            const V3 N{nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]}, L{rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]};
+            const float li = intensity / (tmaxs[i] * tmaxs[i]);                 // rchit:85
+            const float dnl = std::fmax(dot(N, L), 0.0f);                       // wavefront.glsl:25
+            float diff[3] = {mat.diffuse.x * dnl, mat.diffuse.y * dnl, mat.diffuse.z * dnl};
+            if (mat.illum >= 1) { diff[0] += mat.ambient.x; diff[1] += mat.ambient.y; diff[2] += mat.ambient.z; }
+            const float att = (dot(N, L) > 0 && !shadowed[i]) ? 1.0f : 0.3f;    // rchit:98-133 (specular is zero for illum < 2)
+            for (int k = 0; k < 3; ++k) c[k] = li * att * diff[k];
+        }
+        for (int k = 0; k < 3; ++k) {
+            const float g = std::pow(std::fmin(std::fmax(c[k], 0.f), 1.f), 1.0f / 2.2f);  // post.frag:36
+            img[3 * i + k] = (unsigned char)std::lround(g * 255.0f);
+        }
+    }
+    std::ofstream f(file, std::ios::binary);
+    f << "P6\n" << W << " " << H << "\n255\n";
+    f.write(reinterpret_cast<const char*>(img.data()), (std::streamsize)img.size());
+    std::printf("[voxhip] rendered %ux%u to %s: %zu of %zu primary rays hit a voxel\n", W, H, file.c_str(), hits, n);
+    return 0;
+}
+
 template <class T, bool P>
-int run_grid(const std::string& path, float vs, const std::string& dumpFile, const char* label)
+int run_grid(const std::string& path, float vs, const std::string& dumpFile, const char* label, const std::string& renderFile = "",
+             uint32_t rw = 1280, uint32_t rh = 720)
 {
     VoxelBuilder<T, P> voxelBuilder{std::filesystem::path(path)};
     const auto t0 = Clock::now();
@@ -47,6 +137,7 @@ int run_grid(const std::string& path, float vs, const std::string& dumpFile, con
     std::printf("[voxhip] %s: %zu AABBs, %.1f Mvoxels/s build (host wall, incl. launch+sync), %.1f M AABBs/s getAabbs (incl. D2H copy)\n", label,
                 aabbs.size(), cells / sb / 1e6, aabbs.size() / (sa > 0 ? sa : 1e-9) / 1e6);
     dump(dumpFile, aabbs);
+    if (!renderFile.empty()) return render(vox.handle(), renderFile, rw, rh);
     return 0;
 }
 }  // namespace
@@ -54,14 +145,15 @@ int run_grid(const std::string& path, float vs, const std::string& dumpFile, con
 int main(int argc, char** argv)
 {
     if (argc < 3) {  // the reference reads argv[1], argv[2] unchecked (main.cpp:80,163)
-        std::fprintf(stderr, "usage: %s <Path to obj file> <Voxlesize> [--grid bool|aabbstruct|vec|octree] [--parallel] [--dump FILE] [--bench RUNS]\n",
+        std::fprintf(stderr, "usage: %s <Path to obj file> <Voxlesize> [--grid bool|aabbstruct|vec|octree] [--parallel] [--dump FILE] [--bench RUNS] [--render FILE.ppm [--size WxH]]\n",
                      argv[0]);
         return 2;
     }
     const std::string path = argv[1];
     float vs = 0.f;
     try { vs = std::stof(argv[2]); } catch (const std::exception&) { std::fprintf(stderr, "invalid voxel size '%s'\n", argv[2]); return 2; }
-    std::string grid = "bool", dumpFile;
+    std::string grid = "bool", dumpFile, renderFile;
+    uint32_t rw = 1280, rh = 720;  // main.cpp:72-73
     bool parallel = false;
     long benchRuns = 0;
     for (int i = 3; i < argc; ++i) {
@@ -69,6 +161,8 @@ int main(int argc, char** argv)
         else if (!std::strcmp(argv[i], "--parallel")) parallel = true;
         else if (!std::strcmp(argv[i], "--dump") && i + 1 < argc) dumpFile = argv[++i];
         else if (!std::strcmp(argv[i], "--bench") && i + 1 < argc) benchRuns = std::atol(argv[++i]);
+        else if (!std::strcmp(argv[i], "--render") && i + 1 < argc) renderFile = argv[++i];
+        else if (!std::strcmp(argv[i], "--size") && i + 1 < argc) { if (std::sscanf(argv[++i], "%ux%u", &rw, &rh) != 2) { std::fprintf(stderr, "bad --size\n"); return 2; } }
         else { std::fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
     }
     try {
@@ -91,7 +185,7 @@ int main(int argc, char** argv)
             dump(dumpFile, aabbs);
             return 0;
         }
-        if (grid == "bool") return parallel ? run_grid<VoxelGridBool, true>(path, vs, dumpFile, "VoxelGridBool") : run_grid<VoxelGridBool, false>(path, vs, dumpFile, "VoxelGridBool");
+        if (grid == "bool") return parallel ? run_grid<VoxelGridBool, true>(path, vs, dumpFile, "VoxelGridBool", renderFile, rw, rh) : run_grid<VoxelGridBool, false>(path, vs, dumpFile, "VoxelGridBool", renderFile, rw, rh);
         if (grid == "aabbstruct") return parallel ? run_grid<VoxelGridAABBstruct, true>(path, vs, dumpFile, "VoxelGridAABBstruct") : run_grid<VoxelGridAABBstruct, false>(path, vs, dumpFile, "VoxelGridAABBstruct");
         if (grid == "vec") return parallel ? run_grid<VoxelGridVec, true>(path, vs, dumpFile, "VoxelGridVec") : run_grid<VoxelGridVec, false>(path, vs, dumpFile, "VoxelGridVec");
         std::fprintf(stderr, "unknown grid flavour %s\n", grid.c_str());

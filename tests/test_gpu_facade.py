@@ -76,3 +76,26 @@ def test_cli_contract(gpu, tmp_path):
     assert r.returncode == 1 and "Path does not exist!" in r.stdout
     r = run([exe])
     assert r.returncode == 2
+
+
+def test_cli_render(gpu, tmp_path):
+    """--render: the reference's picture of the voxels without Vulkan.  Checks the PPM container, that the
+    number of non-background pixels equals the number of primary-ray hits the library reports for the same camera, and that
+    both lit and shadowed/back-facing shades occur."""
+    v, t = vx_scenes.rotated_cube(half=1.0, offset=(0.0, 1.0, 0.0))
+    obj = tmp_path / "c.obj"
+    vx_scenes.write_obj(str(obj), v, t)
+    ppm = tmp_path / "o.ppm"
+    r = run([os.path.join(PKG, "voxilizer"), str(obj), "0.05", "--render", str(ppm), "--size", "320x180"])
+    assert r.returncode == 0 and "rendered 320x180" in r.stdout, r.stdout
+    raw = open(ppm, "rb").read()
+    assert raw.startswith(b"P6\n320 180\n255\n")
+    img = np.frombuffer(raw[len(b"P6\n320 180\n255\n"):], np.uint8).reshape(180, 320, 3)
+    bg = int(round((0.8 ** (1 / 2.2)) * 255))
+    is_bg = np.all(img == bg, axis=2)
+    g = gpu.Grid.voxelize(gpu.Mesh.from_arrays(v, t), np.float32(0.05))
+    vi, pi = vx_scenes.camera_matrices(aspect=320.0 / 180.0)
+    tt = g.trace_ex(camera=(vi, pi, 320, 180), want=("t",))["t"].reshape(180, 320)
+    assert abs(int((~is_bg).sum()) - int((tt > 0).sum())) <= 2     # the two camera set-ups differ in the last float bits
+    shades = np.unique(img[~is_bg][:, 0])
+    assert len(shades) >= 2 and img[~is_bg][:, 2].max() == 0        # yellow default material: blue channel stays 0
