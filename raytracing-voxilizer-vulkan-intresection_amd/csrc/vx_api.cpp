@@ -144,6 +144,7 @@ struct Small {
     unsigned long long total_a;
     unsigned long long total_b;
     unsigned long long nhits;
+    unsigned long long trace_counters[4];
 };
 
 }  // namespace
@@ -169,18 +170,18 @@ struct vx_grid {
     float bbmin[3] = {0, 0, 0}, bbmax[3] = {0, 0, 0}, bbc[3] = {0, 0, 0};
     uint64_t triangles = 0;
     uint32_t cdim[3] = {0, 0, 0}, c2dim[3] = {0, 0, 0};
-    DevBuf words, cwords, c2words, bricks, bbounds, idxtmp, ttmp, wprefix, recs, units, ubase, btri, umask, hbase, scantmp, small, vec;
+    DevBuf words, cwords, c2words, bricks, bbounds, idxtmp, ttmp, spill, keys, camera, wprefix, recs, units, ubase, btri, umask, hbase, scantmp, small, vec;
     bool coarse_valid = false, prefix_valid = false, counts_valid = true;
     uint64_t occupied = 0, set_calls = 0, host_set_calls = 0;
     uint64_t vec_count = 0;
     void set_dev(int d)
     {
         device = d;
-        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &bbounds, &idxtmp, &ttmp, &wprefix, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec}) b->dev = d;
+        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &bbounds, &idxtmp, &ttmp, &spill, &keys, &camera, &wprefix, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec}) b->dev = d;
     }
     void release_all()
     {
-        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &bbounds, &idxtmp, &ttmp, &wprefix, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec}) b->release();
+        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &bbounds, &idxtmp, &ttmp, &spill, &keys, &camera, &wprefix, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec}) b->release();
     }
 };
 
@@ -785,7 +786,15 @@ static vx_status trace_common(vx_grid* g, vx::TraceIO io)
     mips.w1 = g->cwords.as<uint32_t>();
     mips.w2 = g->c2words.as<uint32_t>();
     for (int a = 0; a < 3; ++a) { mips.d1[a] = g->cdim[a]; mips.d2[a] = g->c2dim[a]; }
-    vx::launch_trace(g->g, mips, prefix, io, &g->small.as<Small>()->nhits, idx_tmp, g->stream);
+    if (io.cam) {
+        VX_HIP(g->camera.ensure(sizeof(vx::Camera)));
+        VX_HIP(hipMemcpyAsync(g->camera.p, io.cam, sizeof(vx::Camera), hipMemcpyHostToDevice, g->stream));
+        VX_HIP(hipStreamSynchronize(g->stream));  // the host copy lives on the caller's stack
+        io.cam_dev = g->camera.as<vx::Camera>();
+    }
+    VX_HIP(g->spill.ensure(vx::trace_spill_bytes(io.nrays)));
+    VX_HIP(g->keys.ensure((size_t)io.nrays * 8 + 8));
+    vx::launch_trace(g->g, mips, prefix, io, g->small.as<Small>()->trace_counters, idx_tmp, g->spill.p, g->keys.as<unsigned long long>(), g->stream);
     VX_HIP(hipGetLastError());
     return VX_OK;
 }

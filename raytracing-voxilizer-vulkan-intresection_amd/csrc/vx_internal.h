@@ -87,7 +87,8 @@ struct TraceMips {
 };
 struct TraceIO {
     const float* rays = nullptr;         // 6 f32 per ray, or null with cam
-    const Camera* cam = nullptr;         // primary rays generated in-kernel
+    const Camera* cam = nullptr;         // primary rays generated in-kernel (host copy)
+    const Camera* cam_dev = nullptr;     // the same camera in device memory (filled in by the API layer)
     uint64_t nrays = 0;
     float tmin = 0.001f, tmax = 10000.0f;
     const float* tmax_per_ray = nullptr; // optional per-ray tMax
@@ -99,9 +100,10 @@ struct TraceIO {
     vx_hit* hits = nullptr;
     unsigned long long* nhits = nullptr;
 };
+size_t trace_spill_bytes(uint64_t nrays);
 void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* word_prefix, const TraceIO& io,
-                  unsigned long long* next_ray /*device work counter*/, unsigned long long* idx_tmp /*nrays x 8 B when ranks are wanted*/,
-                  hipStream_t s);
+                  unsigned long long* counters /*4 device words*/, unsigned long long* idx_tmp /*nrays x 8 B when ranks are wanted*/,
+                  void* spill_buf /*trace_spill_bytes(nrays)*/, unsigned long long* keys /*nrays x 8 B*/, hipStream_t s);
 
 // single-voxel helpers
 void launch_set_bit(uint32_t* words, uint64_t idx, hipStream_t s);

@@ -199,11 +199,11 @@ __device__ __forceinline__ void enter_level(Lane& R, const GridParams& g, float 
 
 // Ray r of the batch: from the ray buffer, or generated from the reference camera model (raytrace.rgen:41-47; mat*vec in glm's
 // association (m0*v0 + m1*v1) + (m2*v2 + m3*v3)).
-template <bool PRIMARY>
-__device__ __forceinline__ void load_ray(uint64_t r, const float* __restrict__ rays, const Camera& cam, float& ox, float& oy, float& oz, float& dx,
-                                         float& dy, float& dz)
+__device__ __forceinline__ void load_ray(bool primary, uint64_t r, const float* __restrict__ rays, const Camera* __restrict__ camp, float& ox, float& oy,
+                                         float& oz, float& dx, float& dy, float& dz)
 {
-    if (PRIMARY) {
+    if (primary) {
+        const Camera& cam = *camp;  // in device memory: 34 dwords of kernel arguments would otherwise sit in (spilled) SGPRs
         const uint32_t px = (uint32_t)(r % cam.width), py = (uint32_t)(r / cam.width);
         const float u = ((float)px + 0.5f) / (float)cam.width, v = ((float)py + 0.5f) / (float)cam.height;
         const float ndx = u * 2.0f - 1.0f, ndy = v * 2.0f - 1.0f;
@@ -225,7 +225,7 @@ __device__ __forceinline__ void load_ray(uint64_t r, const float* __restrict__ r
 }
 
 // Ray set-up: tolerances, grid clip, top-level start.  Returns false when the ray cannot touch the grid.
-__device__ __forceinline__ bool setup_ray(Lane& R, const GridParams& g, const TraceMips& M, float inv_vs, float tmax)
+__device__ __forceinline__ bool setup_ray(Lane& R, const GridParams& g, const TraceMips& M, float inv_vs, float tmax, float seg_t0, float seg_t1)
 {
     R.ix = 1.0f / R.dx; R.iy = 1.0f / R.dy; R.iz = 1.0f / R.dz;  // rint:48
     const float hx = g.org[0] + (float)g.dim[0] * g.vs, hy = g.org[1] + (float)g.dim[1] * g.vs, hz = g.org[2] + (float)g.dim[2] * g.vs;
@@ -241,18 +241,21 @@ __device__ __forceinline__ bool setup_ray(Lane& R, const GridParams& g, const Tr
     R.tauz = R.dz == 0.0f ? 0.0f : tolp * fabsf(R.iz);
     float tn = 0.0f, tf = tmax;
     bool miss = false;
-#define VX_CLIP(o, d, inv, lo, hi)                                                        \
-    if ((d) == 0.0f) { miss |= ((o) < (lo)-tolp) || ((o) > (hi) + tolp); }                 \
-    else {                                                                                 \
-        const float t1 = (((lo)-tolp) - (o)) * (inv), t2 = (((hi) + tolp) - (o)) * (inv);  \
-        tn = fmaxf(tn, fminf(t1, t2));                                                     \
-        tf = fminf(tf, fmaxf(t1, t2));                                                     \
+#define VX_CLIP(o, d, inv, lo, hi)                                                                   \
+    {                                                                                                 \
+        const float t1 = (((lo)-tolp) - (o)) * (inv), t2 = (((hi) + tolp) - (o)) * (inv);             \
+        const bool z = (d) == 0.0f;                                                                   \
+        miss |= z && (((o) < (lo)-tolp) || ((o) > (hi) + tolp));                                      \
+        tn = fmaxf(tn, z ? -INFINITY : fminf(t1, t2));                                                \
+        tf = fminf(tf, z ? INFINITY : fmaxf(t1, t2));                                                 \
     }
     VX_CLIP(R.ox, R.dx, R.ix, g.org[0], hx)
     VX_CLIP(R.oy, R.dy, R.iy, g.org[1], hy)
     VX_CLIP(R.oz, R.dz, R.iz, g.org[2], hz)
 #undef VX_CLIP
     tf += R.taux + R.tauy + R.tauz;
+    tn = fmaxf(tn, seg_t0);  // a ray segment (see k_trace): only the cells overlapping [seg_t0, seg_t1] are walked
+    tf = fminf(tf, seg_t1);
     R.tn = tn;
     R.tf = tf;
     R.best = INFINITY;
@@ -289,12 +292,13 @@ __device__ __forceinline__ void brick_test(Lane& R, const GridParams& g, const T
     const float tauS = R.taux + R.tauy + R.tauz;
     float ta = R.tn, tb = fminf(R.tf, R.best + tauS);
     // the ray inside the dilated brick
-#define VX_CLIPB(o, d, inv, lo, hi)                                                         \
-    if ((d) == 0.0f) { if ((o) < (lo)-tolp || (o) > (hi) + tolp) return; }                   \
-    else {                                                                                   \
-        const float t1 = (((lo)-tolp) - (o)) * (inv), t2 = (((hi) + tolp) - (o)) * (inv);    \
-        ta = fmaxf(ta, fminf(t1, t2));                                                       \
-        tb = fminf(tb, fmaxf(t1, t2));                                                       \
+    // branch-free: a zero direction component makes the slab unbounded in t when the origin is inside it, empty otherwise
+#define VX_CLIPB(o, d, inv, lo, hi)                                                                  \
+    {                                                                                                 \
+        const float t1 = (((lo)-tolp) - (o)) * (inv), t2 = (((hi) + tolp) - (o)) * (inv);             \
+        const bool z = (d) == 0.0f, out = ((o) < (lo)-tolp) || ((o) > (hi) + tolp);                   \
+        ta = fmaxf(ta, z ? (out ? INFINITY : -INFINITY) : fminf(t1, t2));                             \
+        tb = fminf(tb, z ? INFINITY : fmaxf(t1, t2));                                                 \
     }
     VX_CLIPB(R.ox, R.dx, R.ix, lox, hix)
     VX_CLIPB(R.oy, R.dy, R.iy, loy, hiy)
@@ -323,11 +327,12 @@ __device__ __forceinline__ void brick_test(Lane& R, const GridParams& g, const T
     for (int k = 0; k <= s1 - s0; ++k) {
         const int s = zfwd ? s0 + k : s1 - k;
         float tsa = ta, tsb = tb;
-        if (R.dz != 0.0f) {
+        {
             const float pl = g.org[2] + (float)(fz + s) * vs, ph = g.org[2] + (float)(fz + s + 1) * vs;
             const float t1 = ((pl - tolp) - R.oz) * R.iz, t2 = ((ph + tolp) - R.oz) * R.iz;
-            tsa = fmaxf(tsa, fminf(t1, t2));
-            tsb = fminf(tsb, fmaxf(t1, t2));
+            const bool zd = R.dz == 0.0f;  // then the slice range [s0, s1] already is the set of slices the origin can be in
+            tsa = fmaxf(tsa, zd ? -INFINITY : fminf(t1, t2));
+            tsb = fminf(tsb, zd ? INFINITY : fmaxf(t1, t2));
         }
         if (!(tsa <= tsb)) continue;
         const unsigned long long bits = bp[s];
@@ -340,11 +345,12 @@ __device__ __forceinline__ void brick_test(Lane& R, const GridParams& g, const T
                 const uint32_t rowbits = (uint32_t)(bits >> (8 * r)) & 0xFFu;
                 if (!rowbits) continue;
                 float tra = tsa, trb = tsb;
-                if (R.dy != 0.0f) {
+                {
                     const float pl = g.org[1] + (float)(fy + r) * vs, ph = g.org[1] + (float)(fy + r + 1) * vs;
                     const float t1 = ((pl - tolp) - R.oy) * R.iy, t2 = ((ph + tolp) - R.oy) * R.iy;
-                    tra = fmaxf(tra, fminf(t1, t2));
-                    trb = fminf(trb, fmaxf(t1, t2));
+                    const bool zd = R.dy == 0.0f;
+                    tra = fmaxf(tra, zd ? -INFINITY : fminf(t1, t2));
+                    trb = fminf(trb, zd ? INFINITY : fmaxf(t1, t2));
                 }
                 if (!(tra <= trb)) continue;
                 const float xa = R.ox + tra * R.dx, xb = R.ox + trb * R.dx;
@@ -488,15 +494,41 @@ __device__ __forceinline__ bool upper_step(Lane& R, const GridParams& g, const T
 
 }  // namespace
 
-// Persistent waves with dynamic ray fetch.  Exit condition every wave reaches: the counter passes nrays (no refill
-// possible) and every lane's ray has finished; each ray finishes in a bounded number of steps.
-template <bool PRIMARY, bool LDS_M1, bool ANYHIT>
-__global__ __launch_bounds__(256) void k_trace(GridParams g, TraceMips M, const float* __restrict__ rays, Camera cam, uint64_t nrays, float tmin,
-                                               float tmax, const float* __restrict__ tmax_per_ray, float* __restrict__ t_out, unsigned long long* __restrict__ idx_out,
-                                               uint8_t* __restrict__ shadowed_out,
-                                               unsigned long long* next_ray, uint32_t m1_words, int kStepsPerRound, int kRefillBelow,
-                                               int kItersPerRound, int kChunkRays)
+// One spilled ray: the main pass gave up on it after its step budget; [t0, tf] is what is left to walk.
+struct __attribute__((aligned(16))) Spill {
+    uint32_t ray;
+    float t0, tf;          // restart time (entry of the cell it was in), end of the useful interval
+    float best;            // best accepted t so far (+inf: none)
+    unsigned long long best_idx;
+    unsigned long long pad;
+};
+static_assert(sizeof(Spill) == 32, "Spill must be 32 bytes");
+
+__device__ __forceinline__ unsigned long long pack_key(float t, unsigned long long idx) { return ((unsigned long long)__float_as_uint(t) << 32) | (uint32_t)idx; }
+
+// Persistent waves with dynamic work fetch.  Exit condition every wave reaches: the work counter passes the item count (no
+// refill possible) and every lane's item has finished; each item finishes in a bounded number of steps.
+//
+// Two passes of the same kernel bound the serial chain of a single ray (on 1M incoherent rays the kernel time WAS the
+// longest ray: ~270 steps at ~2.8 us, with 4 waves sharing a SIMD's issue):
+//   SEGMENTS=false  work item = ray.  A ray that exceeds `budget` steps is SPILLED: its remaining interval goes to a list.
+//   SEGMENTS=true   work item = (spilled ray, k of nseg): the k-th equal slice of the remaining t interval, walked
+//                   independently (every cell overlapping the slice, with the usual probes); results meet in a 64-bit
+//                   atomicMin of (t bits << 32 | voxel index) -- the same "closest, then lower index" order the
+//                   single-walk uses.  k_merge then writes the spilled rays' outputs.
+template <bool LDS_M1, bool SEGMENTS>
+__global__ __launch_bounds__(256) void k_trace(GridParams g, TraceMips M, const float* __restrict__ rays, const Camera* __restrict__ cam, uint64_t nrays,
+                                               float tmin,
+                                               float tmax, const float* __restrict__ tmax_per_ray, int any_hit, float* __restrict__ t_out,
+                                               unsigned long long* __restrict__ idx_out, uint8_t* __restrict__ shadowed_out,
+                                               unsigned long long* next_item, Spill* __restrict__ spill, unsigned long long* nspill,
+                                               unsigned long long* __restrict__ keys, int budget, int nseg, uint32_t m1_words)
 {
+    // tuned on the bench workload (tools/trace_sweep.sh); the kernel is insensitive to them within +-5 %
+    constexpr int kStepsPerRound = 4;   // upper-level steps between two brick-test phases
+    constexpr int kItersPerRound = 2;   // (walk, brick test) iterations between two refill checks
+    constexpr int kRefillBelow = 44;    // refill when fewer than this many lanes are busy
+    constexpr int kChunkRays = 64;      // items a wave reserves per touch of the global counter
     extern __shared__ __attribute__((aligned(16))) uint32_t m1_lds[];
     if (LDS_M1) {
         for (uint32_t i = threadIdx.x; i < m1_words; i += 256u) m1_lds[i] = M.w1[i];
@@ -504,14 +536,16 @@ __global__ __launch_bounds__(256) void k_trace(GridParams g, TraceMips M, const 
     }
     const int lane = threadIdx.x & 63;
     const float inv_vs = 1.0f / g.vs;
+    const bool primary = rays == nullptr;
+    const uint64_t nitems = SEGMENTS ? *nspill * (uint64_t)nseg : nrays;
     Lane R;
     uint64_t r = ~0ull;      // ray this lane is tracing (~0: none)
     bool busy = false;       // traversal in progress
-    bool drained = false;    // no ray left for this wave: the global counter and the wave's chunk are exhausted
+    bool drained = false;    // no item left for this wave: the global counter and the wave's chunk are exhausted
     bool drained_global = false;
-    const uint64_t kChunk = (uint64_t)kChunkRays;  // rays a wave reserves per touch of the global counter
+    const uint64_t kChunk = (uint64_t)kChunkRays;  // items a wave reserves per touch of the global counter
     uint64_t chunk_cur = 0, chunk_end = 0;
-    int steps_left = 0;      // safety cap per ray
+    int steps_left = 0;      // step budget of the current item
 #ifdef VX_TRACE_DEBUG_CYCLES
     unsigned long long dbg_t0 = 0;
 #endif
@@ -519,8 +553,7 @@ __global__ __launch_bounds__(256) void k_trace(GridParams g, TraceMips M, const 
         const unsigned long long busy_mask = __ballot(busy);
         const int nbusy = __popcll(busy_mask);
         if (!drained && nbusy < kRefillBelow) {
-            // ---- refill idle lanes.  Ray indices come from a per-wave chunk; the global counter is touched once per chunk
-            // (an atomic round trip per refill sat on every round's critical path).
+            // ---- refill idle lanes.  Item indices come from a per-wave chunk; the global counter is touched once per chunk.
             const unsigned long long idle_mask = ~busy_mask;
             const uint64_t need = (uint64_t)(64 - nbusy);
             const uint64_t take = need < chunk_end - chunk_cur ? need : chunk_end - chunk_cur;
@@ -529,33 +562,55 @@ __global__ __launch_bounds__(256) void k_trace(GridParams g, TraceMips M, const 
             uint64_t second = 0;
             if (take < need) {
                 unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(next_ray, (unsigned long long)kChunk);
+                if (lane == 0) base = atomicAdd(next_item, (unsigned long long)kChunk);
                 base = ((unsigned long long)__shfl((unsigned)(base >> 32), 0, 64) << 32) | __shfl((unsigned)base, 0, 64);
                 second = base;
                 chunk_cur = base + (need - take);
                 chunk_end = base + kChunk;
-                if (chunk_end > nrays) chunk_end = nrays > base ? nrays : base;
+                if (chunk_end > nitems) chunk_end = nitems > base ? nitems : base;
                 if (chunk_cur > chunk_end) chunk_cur = chunk_end;
-                if (base + kChunk >= nrays) drained_global = true;
+                if (base + kChunk >= nitems) drained_global = true;
             }
             if (drained_global && chunk_cur >= chunk_end) drained = true;
             if (!busy) {
                 const uint64_t pos = (uint64_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
-                const uint64_t mine = pos < take ? first + pos : (take < need ? second + (pos - take) : nrays);
-                if (mine < nrays) {
-                    r = mine;
-                    load_ray<PRIMARY>(r, rays, cam, R.ox, R.oy, R.oz, R.dx, R.dy, R.dz);
+                const uint64_t mine = pos < take ? first + pos : (take < need ? second + (pos - take) : nitems);
+                if (mine < nitems) {
+                    float seg_a = 0.0f, seg_b = INFINITY, best0 = INFINITY;
+                    unsigned long long bidx0 = ~0ull;
+                    bool skip = false;
+                    if (SEGMENTS) {
+                        const Spill e = spill[mine / (uint64_t)nseg];
+                        const int k = (int)(mine % (uint64_t)nseg);
+                        r = e.ray;
+                        const float span = e.tf - e.t0;
+                        seg_a = e.t0 + span * ((float)k / (float)nseg);
+                        seg_b = k == nseg - 1 ? e.tf : e.t0 + span * ((float)(k + 1) / (float)nseg);
+                        best0 = e.best;
+                        bidx0 = e.best_idx;
+                    } else {
+                        r = mine;
+                    }
+                    load_ray(primary, r, rays, cam, R.ox, R.oy, R.oz, R.dx, R.dy, R.dz);
                     const float tmax_r = tmax_per_ray ? tmax_per_ray[r] : tmax;
                     R.tmax = tmax_r;
-                    busy = setup_ray(R, g, M, inv_vs, tmax_r);
+                    busy = setup_ray(R, g, M, inv_vs, tmax_r, seg_a, seg_b);
+                    if (SEGMENTS) {
+                        R.best = best0;
+                        R.best_idx = bidx0;
+                        skip = best0 + R.tau_term < seg_a;  // a hit found before the spill already precedes this slice
+                        if (skip) busy = false;
+                    }
 #ifdef VX_TRACE_DEBUG_CYCLES
                     dbg_t0 = wall_clock64();
 #endif
-                    steps_left = 1 << 20;
-                    if (!busy) {  // cannot touch the grid: retire at once as a miss
-                        if (t_out) t_out[r] = -1.0f;
-                        if (idx_out) idx_out[r] = ~0ull;
-                        if (shadowed_out) shadowed_out[r] = 0;
+                    steps_left = (!SEGMENTS && budget > 0) ? budget : (1 << 20);
+                    if (!busy) {  // cannot touch the grid / nothing to do: retire at once
+                        if (!SEGMENTS) {
+                            if (t_out) t_out[r] = -1.0f;
+                            if (idx_out) idx_out[r] = ~0ull;
+                            if (shadowed_out) shadowed_out[r] = 0;
+                        }
                         r = ~0ull;
                     }
                 }
@@ -566,15 +621,16 @@ __global__ __launch_bounds__(256) void k_trace(GridParams g, TraceMips M, const 
             continue;
         }
         // ---- trace, in two phases so that the wave's lanes run the same code together:
-        // (1) upper-level walk until the lane has an occupied brick pending (or its ray is finished),
+        // (1) upper-level walk until the lane has an occupied brick pending (or its ray is finished / out of budget),
         // (2) the brick test for every lane with a pending brick.
-        bool finished = false;
+        bool finished = false, over = false;
         for (int it = 0; it < kItersPerRound; ++it) {
             for (int k = 0; k < kStepsPerRound; ++k) {
-                const bool go = busy && !finished && !R.pending;
+                const bool go = busy && !finished && !over && !R.pending;
                 if (!__ballot(go)) break;
                 if (go) {
-                    if (!upper_step<LDS_M1>(R, g, M, m1_lds, inv_vs) || --steps_left <= 0) finished = true;
+                    if (!upper_step<LDS_M1>(R, g, M, m1_lds, inv_vs)) finished = true;
+                    else if (--steps_left <= 0) over = true;
                 }
             }
             const bool pend = busy && R.pending;
@@ -583,34 +639,81 @@ __global__ __launch_bounds__(256) void k_trace(GridParams g, TraceMips M, const 
                 brick_test(R, g, M, inv_vs, R.tolp, R.bx, R.by, R.bz, tmin, R.tmax);
                 R.pending = false;
                 // shadow query (gl_RayFlagsTerminateOnFirstHitEXT, raytrace2.rchit:108): any accepted hit ends the ray
-                if (ANYHIT && R.best_idx != ~0ull) finished = true;
+                if (any_hit && R.best_idx != ~0ull) finished = true;
             }
         }
-        // ---- retire: t and the voxel index of the hit; the primitive rank (two dependent loads) and the hit compaction are
-        // done by k_rank over all rays afterwards, off this kernel's critical path
+        if (over && !finished) {
+            if (SEGMENTS || !spill) {
+                over = false;  // segments (and runs without a spill list) have no budget: keep going
+                steps_left = 1 << 20;
+            }
+        }
+        // ---- spill (main pass): hand the rest of an over-budget ray to the segment pass
+        {
+            const bool sp = !SEGMENTS && over && !finished;
+            const unsigned long long sbal = __ballot(sp);
+            if (sbal) {
+                unsigned long long sb = 0;
+                if (lane == 0) sb = atomicAdd(nspill, (unsigned long long)__popcll(sbal));
+                sb = ((unsigned long long)__shfl((unsigned)(sb >> 32), 0, 64) << 32) | __shfl((unsigned)sb, 0, 64);
+                if (sp) {
+                    Spill e;
+                    e.ray = (uint32_t)r;
+                    e.t0 = fmaxf(R.t_in, R.tn);   // the cell it is in is walked again from its entry
+                    e.tf = fminf(R.tf, R.best + R.tau_term);
+                    e.best = R.best;
+                    e.best_idx = R.best_idx;
+                    e.pad = 0;
+                    spill[sb + __popcll(sbal & ((1ull << lane) - 1ull))] = e;
+                    keys[r] = R.best_idx != ~0ull ? pack_key(R.best, R.best_idx) : ~0ull;
+                    busy = false;
+                    r = ~0ull;
+                }
+            }
+        }
+        // ---- retire: t and the voxel index of the hit; the primitive rank (two dependent loads), the normal and the hit
+        // compaction are done by k_rank over all rays afterwards, off this kernel's critical path
         if (finished) {
-            float best_t = R.best_idx != ~0ull ? R.best : -1.0f;
+            if (SEGMENTS) {
+                if (R.best_idx != ~0ull) atomicMin(&keys[r], pack_key(R.best, R.best_idx));
+            } else {
+                float best_t = R.best_idx != ~0ull ? R.best : -1.0f;
 #ifdef VX_TRACE_DEBUG_CYCLES
-            best_t = (float)(wall_clock64() - dbg_t0);  // diagnostic build: report the ray's residency in 100 MHz ticks
+                best_t = (float)(wall_clock64() - dbg_t0);  // diagnostic build: report the ray's residency in 100 MHz ticks
 #endif
 #ifdef VX_TRACE_DEBUG_STEPS
-            best_t = (float)((1 << 20) - steps_left);  // diagnostic build: report the step count instead of t
+                best_t = (float)((1 << 20) - steps_left);  // diagnostic build: report the step count instead of t
 #endif
-            if (t_out) t_out[r] = best_t;
-            if (idx_out) idx_out[r] = R.best_idx;
-            if (shadowed_out) shadowed_out[r] = R.best_idx != ~0ull ? 1 : 0;
+                if (t_out) t_out[r] = best_t;
+                if (idx_out) idx_out[r] = R.best_idx;
+                if (shadowed_out) shadowed_out[r] = R.best_idx != ~0ull ? 1 : 0;
+            }
             busy = false;
             r = ~0ull;
         }
     }
 }
 
+// outputs of the spilled rays from their merged keys
+__global__ __launch_bounds__(256) void k_merge(const Spill* __restrict__ spill, const unsigned long long* __restrict__ nspill,
+                                               const unsigned long long* __restrict__ keys, float* __restrict__ t_out,
+                                               unsigned long long* __restrict__ idx_out, uint8_t* __restrict__ shadowed_out)
+{
+    const unsigned long long n = *nspill;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256u) {
+        const uint32_t r = spill[i].ray;
+        const unsigned long long k = keys[r];
+        if (t_out) t_out[r] = k == ~0ull ? -1.0f : __uint_as_float((uint32_t)(k >> 32));
+        if (idx_out) idx_out[r] = k == ~0ull ? ~0ull : (k & 0xFFFFFFFFull);
+        if (shadowed_out) shadowed_out[r] = k == ~0ull ? 0 : 1;
+    }
+}
+
 // Per-ray post-pass over all rays: primitive id (== gl_PrimitiveID: rank of the voxel in the ascending AABB list), the
 // cube-face normal of raytrace2.rchit:60-73, and wavefront hit compaction.
-template <bool PRIMARY>
 __global__ __launch_bounds__(256) void k_rank(const float* __restrict__ t, const unsigned long long* __restrict__ idx, uint64_t nrays, GridParams g,
                                               const uint32_t* __restrict__ words, const uint32_t* __restrict__ word_prefix, const float* __restrict__ rays,
-                                              Camera cam, uint32_t* __restrict__ prim_out, float* __restrict__ normal_out, vx_hit* __restrict__ hits,
+                                              const Camera* __restrict__ cam, uint32_t* __restrict__ prim_out, float* __restrict__ normal_out, vx_hit* __restrict__ hits,
                                               unsigned long long* nhits)
 {
     const uint64_t r = (uint64_t)blockIdx.x * 256u + threadIdx.x;
@@ -632,7 +735,7 @@ __global__ __launch_bounds__(256) void k_rank(const float* __restrict__ t, const
                 const uint32_t y = rem / g.dim[0], x = rem - y * g.dim[0];
                 float bb[6], ox, oy, oz, dx, dy, dz;
                 cell_aabb(g, x, y, z, bb);
-                load_ray<PRIMARY>(r, rays, cam, ox, oy, oz, dx, dy, dz);
+                load_ray(rays == nullptr, r, rays, cam, ox, oy, oz, dx, dy, dz);
                 // worldPos = origin + direction * t; worldNrm = normalize(worldPos - (min + max) * 0.5)      rchit:60-65
                 const float vx_ = (ox + dx * tt) - ((bb[0] + bb[3]) * 0.5f);
                 const float vy_ = (oy + dy * tt) - ((bb[1] + bb[4]) * 0.5f);
@@ -666,42 +769,49 @@ __global__ __launch_bounds__(256) void k_rank(const float* __restrict__ t, const
     }
 }
 
-void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* word_prefix, const TraceIO& io, unsigned long long* next_ray,
-                  unsigned long long* idx_tmp, hipStream_t s)
+size_t trace_spill_bytes(uint64_t nrays) { return (size_t)nrays * sizeof(Spill) + 64; }
+
+void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* word_prefix, const TraceIO& io, unsigned long long* counters /*>= 4*/,
+                  unsigned long long* idx_tmp, void* spill_buf, unsigned long long* keys, hipStream_t s)
 {
     const uint64_t nrays = io.nrays;
     if (!nrays) return;
-    (void)hipMemsetAsync(next_ray, 0, sizeof(unsigned long long), s);
-    Camera c{};
-    if (io.cam) c = *io.cam;
+    // counters[0]: work counter of the main pass, [1]: number of spilled rays, [2]: work counter of the segment pass
+    (void)hipMemsetAsync(counters, 0, 3 * sizeof(unsigned long long), s);
+    const Camera* c = io.cam_dev;  // device copy of the camera (null for explicit rays)
     const uint64_t n1 = (uint64_t)mips.d1[0] * mips.d1[1] * mips.d1[2];
     const uint32_t m1_words = (uint32_t)((n1 + 31) / 32);
     const bool lds_m1 = (size_t)m1_words * 4 <= 40960;  // 4 workgroups x 40 KiB fit the CU's 160 KiB
     // persistent grid: 256 CUs x 4 resident 256-thread workgroups, fewer when there are not that many rays
     static const int env_blocks = getenv("VOXHIP_TRACE_BLOCKS") ? atoi(getenv("VOXHIP_TRACE_BLOCKS")) : 1024;
-    static const int env_steps = getenv("VOXHIP_TRACE_STEPS") ? atoi(getenv("VOXHIP_TRACE_STEPS")) : 8;
-    static const int env_iters = getenv("VOXHIP_TRACE_ITERS") ? atoi(getenv("VOXHIP_TRACE_ITERS")) : 4;
-    static const int env_chunk = getenv("VOXHIP_TRACE_CHUNK") ? atoi(getenv("VOXHIP_TRACE_CHUNK")) : 64;
-    static const int env_refill = getenv("VOXHIP_TRACE_REFILL") ? atoi(getenv("VOXHIP_TRACE_REFILL")) : 44;
+    // ray splitting is OFF by default: measured on 1M incoherent rays it costs more than it saves (0.82 ms single pass vs
+    // 0.86-0.97 ms split) -- the kernel is bound by instruction issue at low lane utilisation, not by its longest ray
+    static const int env_budget = getenv("VOXHIP_TRACE_BUDGET") ? atoi(getenv("VOXHIP_TRACE_BUDGET")) : 0;
+    static const int env_nseg = getenv("VOXHIP_TRACE_NSEG") ? atoi(getenv("VOXHIP_TRACE_NSEG")) : 8;
     uint64_t nblk = (nrays + 255) / 256;
     if (nblk > (uint64_t)env_blocks) nblk = (uint64_t)env_blocks;
     const dim3 grid((unsigned)nblk), block(256);
     const bool want_rank = (io.prim_out || io.hits || io.normal_out) && word_prefix && idx_tmp && io.t_out;
     unsigned long long* idx_out = want_rank ? idx_tmp : nullptr;
     const size_t shmem = lds_m1 ? (size_t)m1_words * 4 : 0;
-#define VX_LAUNCH(P, L, A)                                                                                                                        \
-    VX_KL((k_trace<P, L, A>), grid, block, shmem, s, g, mips, io.rays, c, nrays, io.tmin, io.tmax, io.tmax_per_ray, io.t_out, idx_out, io.shadowed_out, \
-          next_ray, m1_words, env_steps, env_refill, env_iters, env_chunk)
-#define VX_LAUNCH2(P, L) do { if (io.any_hit) VX_LAUNCH(P, L, true); else VX_LAUNCH(P, L, false); } while (0)
-    if (io.cam) { if (lds_m1) VX_LAUNCH2(true, true); else VX_LAUNCH2(true, false); }
-    else { if (lds_m1) VX_LAUNCH2(false, true); else VX_LAUNCH2(false, false); }
-#undef VX_LAUNCH2
+    // ray splitting needs the voxel index in 32 bits of the merge key and rays numbered in 32 bits
+    const bool split = env_budget > 0 && env_nseg > 1 && spill_buf && keys && g.nvox <= 0x100000000ull && nrays < 0xFFFFFFFFull;
+    Spill* sp = split ? (Spill*)spill_buf : nullptr;
+    const int budget = split ? env_budget : 0;
+#define VX_LAUNCH(L, SEG, GRID, CNT)                                                                                                             \
+    VX_KL((k_trace<L, SEG>), GRID, block, shmem, s, g, mips, io.rays, c, nrays, io.tmin, io.tmax, io.tmax_per_ray, io.any_hit ? 1 : 0, io.t_out, idx_out, \
+          io.shadowed_out, CNT, sp, counters + 1, keys, budget, env_nseg, m1_words)
+    if (lds_m1) VX_LAUNCH(true, false, grid, counters); else VX_LAUNCH(false, false, grid, counters);
+    if (split) {
+        const dim3 sgrid((unsigned)env_blocks);
+        if (lds_m1) VX_LAUNCH(true, true, sgrid, counters + 2); else VX_LAUNCH(false, true, sgrid, counters + 2);
+        VX_KL(k_merge, dim3(256), block, 0, s, sp, counters + 1, keys, io.t_out, idx_out, io.shadowed_out);
+    }
 #undef VX_LAUNCH
     if (want_rank) {
         if (io.hits && io.nhits) (void)hipMemsetAsync(io.nhits, 0, sizeof(unsigned long long), s);
         const dim3 rgrid((unsigned)((nrays + 255) / 256));
-        if (io.cam) VX_KL(k_rank<true>, rgrid, block, 0, s, io.t_out, idx_tmp, nrays, g, mips.w0, word_prefix, io.rays, c, io.prim_out, io.normal_out, io.hits, io.nhits);
-        else VX_KL(k_rank<false>, rgrid, block, 0, s, io.t_out, idx_tmp, nrays, g, mips.w0, word_prefix, io.rays, c, io.prim_out, io.normal_out, io.hits, io.nhits);
+        VX_KL(k_rank, rgrid, block, 0, s, io.t_out, idx_tmp, nrays, g, mips.w0, word_prefix, io.rays, c, io.prim_out, io.normal_out, io.hits, io.nhits);
     }
 }
 
