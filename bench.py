@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--rays", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-ray-sample", type=int, default=1500)
+    ap.add_argument("--big-rays", type=int, default=8_000_000, help="extra untimed-for-`value` measurement: trace throughput on a large batch (0 = skip)")
     ap.add_argument("--flavour", default="vec", choices=["vec", "bool"],
                     help="vec: VoxelGridVec build (BASELINE configs[2]); bool: VoxelGridBool build + K4 getAabbs (the app's default path)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; the driver's multi-GPU runs) or gloo (rehearsal)")
@@ -167,6 +168,24 @@ def main():
     value = total_rays * a.steps / dt / 1e6
 
     hits = int((d_t > 0).sum().item())
+    # throughput regime of the ray kernel: at 1M rays the persistent kernel holds only 4 rays per lane and is dominated by its
+    # ramp/tail; a large batch shows the steady-state rate (reported separately, never as `value`)
+    big = None
+    if a.big_rays and rank == 0:
+        rb = vx_scenes.random_rays(a.big_rays, verts.min(0), verts.max(0), seed=77)
+        d_rb = torch.from_numpy(rb).to(dev)
+        d_tb = torch.empty(a.big_rays, dtype=torch.float32, device=dev)
+        d_pb = torch.empty(a.big_rays, dtype=torch.int32, device=dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        grid.trace_device(d_rb.data_ptr(), a.big_rays, d_tb.data_ptr(), d_pb.data_ptr())
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(3):
+            grid.trace_device(d_rb.data_ptr(), a.big_rays, d_tb.data_ptr(), d_pb.data_ptr())
+        e1.record()
+        torch.cuda.synchronize()
+        big = {"rays": a.big_rays, "ms": round(e0.elapsed_time(e1) / 3, 4), "mrays_per_s": round(a.big_rays * 3 / (e0.elapsed_time(e1) * 1e-3) / 1e6, 1)}
+        del d_rb, d_tb, d_pb
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -188,9 +207,17 @@ def main():
         avg_ms = ms / max(n, 1)
         ab = alg_bytes.get(dom)
         ach = (ab / (avg_ms * 1e-3) / 1e9) if ab else None
+        traffic = None
+        try:  # HBM bytes per launch from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this workload (profiles/, committed)
+            with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as fh:
+                tj = json.load(fh)
+            if tj.get("workload") == a.scene and tj.get("rays") == R and tj.get("grid") == a.grid:
+                traffic = tj["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
+        except (OSError, ValueError):
+            pass
         roof = {"bound": "hbm", "kernel": dom, "avg_launch_ms": round(avg_ms, 5), "launches": int(n),
                 "algorithmic_bytes": ab, "achieved": round(ach, 2) if ach else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 5) if ach else None, "traffic": None,
+                "frac": round(ach / HBM_PEAK_GBS, 5) if ach else None, "traffic": traffic,
                 "note": "VALU/latency-bound kernel: algorithmic HBM bytes are tiny next to its arithmetic; traffic from rocprofv3 PMC passes is in profiles/"}
     kernels = {k: {"avg_ms": round(v[0] / max(v[1], 1), 5), "launches_per_step": round(v[1] / a.steps, 2)} for k, v in sorted(kern.items())}
 
@@ -210,6 +237,10 @@ def main():
         "stages_ms": {"voxelize": round(float(stage_ms[0]), 4), "exchange": round(float(stage_ms[1]), 4),
                       "get_aabbs": round(float(stage_ms[2]), 4), "trace": round(float(stage_ms[3]), 4)},
         "occupied_voxels": int(nocc), "set_calls": gd["set_calls"], "ray_hits_rank0": hits,
+        "trace_large_batch": big,
+        "kernel_rooflines": {k: {"achieved_GBps": round(alg_bytes[k] / (kern[k][0] / max(kern[k][1], 1) * 1e-3) / 1e9, 1),
+                                 "frac_of_8TBps": round(alg_bytes[k] / (kern[k][0] / max(kern[k][1], 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                             for k in alg_bytes if k in kern},
         "kernels": kernels, "roofline": roof, "cpu_baseline": cpu,
     }
     print(json.dumps(out))
