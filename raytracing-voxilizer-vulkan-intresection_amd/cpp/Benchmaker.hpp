@@ -1,9 +1,12 @@
-// Benchmaker.hpp -- the reference's N-run benchmark harness (src/hello_vulkan.h:172-241), same printout, so the two builds
-// can be A/B-compared by upstream users.  Times are whole milliseconds like upstream (duration_cast<milliseconds>).
+// Benchmaker.hpp -- the reference's N-run benchmark harness (src/hello_vulkan.h:172-241) for A/B runs against upstream:
+// same class template, constructor and printed lines (typos included: upstream's output is the contract), whole
+// milliseconds like upstream's duration_cast<milliseconds>.
 #pragma once
 #include <chrono>
+#include <cstdint>
 #include <cstdio>
 #include <filesystem>
+#include <numeric>
 #include <vector>
 
 #include "VoxelBuilder.hpp"
@@ -12,51 +15,44 @@
 template <DerivedFromVoxelGrid T, bool UseOctree = false>
 class Benchmaker final
 {
-    const float m_voxelSize;
-    const std::filesystem::path m_path;
-    std::vector<std::chrono::milliseconds> m_VoxelBuildTime;
-    std::vector<std::chrono::milliseconds> m_AABBBuildTime;
-    uint64_t m_MemConsume = 0;
+    using Ms = std::chrono::milliseconds;
+    using Clock = std::chrono::high_resolution_clock;
 
-    void runBenachmark()
-    {
-        VoxelBuilder<T> voxelBuilder(m_path);
-        const auto t0 = std::chrono::high_resolution_clock::now();
-        T vox = voxelBuilder.buildVoxelGrid(m_voxelSize);
-        const auto t1 = std::chrono::high_resolution_clock::now();
-        const std::vector<Aabb> aabbs = vox.getAabbs();
-        const auto t2 = std::chrono::high_resolution_clock::now();
-        m_VoxelBuildTime.push_back(std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0));
-        m_AABBBuildTime.push_back(std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1));
-        m_MemConsume = vox.getMemoryUsageBytes();
-    }
+    std::vector<long long> m_buildMs, m_aabbMs;
+    std::uint64_t m_bytes = 0;
 
-    void runBenachmarkOctree()
+    template <class Build>
+    void timeOnce(Build&& build)
     {
-        const auto t0 = std::chrono::high_resolution_clock::now();
-        Octree tree{std::filesystem::path(m_path), m_voxelSize};
-        const auto t1 = std::chrono::high_resolution_clock::now();
-        const std::vector<Aabb> aabbs = tree.getAabbs();
-        const auto t2 = std::chrono::high_resolution_clock::now();
-        m_VoxelBuildTime.push_back(std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0));
-        m_AABBBuildTime.push_back(std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1));
-        m_MemConsume = tree.getMemoryUsageBytes();
+        const auto t0 = Clock::now();
+        auto structure = build();                 // VoxelBuilder<T>::buildVoxelGrid or Octree{...}
+        const auto t1 = Clock::now();
+        const auto boxes = structure.getAabbs();  // timed separately, as upstream does
+        const auto t2 = Clock::now();
+        (void)boxes;
+        m_buildMs.push_back(std::chrono::duration_cast<Ms>(t1 - t0).count());
+        m_aabbMs.push_back(std::chrono::duration_cast<Ms>(t2 - t1).count());
+        m_bytes = structure.getMemoryUsageBytes();
     }
 
 public:
-    Benchmaker(const std::filesystem::path& path, float voxelSize, size_t runs) : m_voxelSize(voxelSize), m_path(path)
+    Benchmaker(const std::filesystem::path& path, float voxelSize, size_t runs)
     {
-        for (size_t i = 0; i < runs; i++) {
-            if constexpr (UseOctree) runBenachmarkOctree();
-            else runBenachmark();
+        for (size_t i = 0; i < runs; ++i) {
+            if constexpr (UseOctree) {
+                timeOnce([&] { return Octree{path, voxelSize}; });
+            } else {
+                VoxelBuilder<T> builder(path);  // the parse is outside the timed region (hello_vulkan.h:184)
+                timeOnce([&] { return builder.buildVoxelGrid(voxelSize); });
+            }
+            std::printf("\n");
         }
-        long long sumVoxel = 0;
-        for (const auto& d : m_VoxelBuildTime) { std::printf("\n"); sumVoxel += d.count(); }
-        std::printf("Voxel build took on avrage %gms\n", static_cast<double>(sumVoxel) / m_VoxelBuildTime.size());
-        long long sumAABB = 0;
-        for (const auto& d : m_AABBBuildTime) sumAABB += d.count();
-        std::printf("AABB build took on avrage %gms\n", static_cast<double>(sumAABB) / m_AABBBuildTime.size());
-        std::printf("Mem constium build took on avrage %llukb\n", (unsigned long long)m_MemConsume);
-        std::printf("Both together took an average build took on avrage %gms\n", static_cast<double>(sumAABB + sumVoxel) / m_AABBBuildTime.size());
+        const double n = static_cast<double>(m_buildMs.size());
+        const long long sb = std::accumulate(m_buildMs.begin(), m_buildMs.end(), 0ll);
+        const long long sa = std::accumulate(m_aabbMs.begin(), m_aabbMs.end(), 0ll);
+        std::printf("Voxel build took on avrage %gms\n", sb / n);
+        std::printf("AABB build took on avrage %gms\n", sa / n);
+        std::printf("Mem constium build took on avrage %llukb\n", static_cast<unsigned long long>(m_bytes));
+        std::printf("Both together took an average build took on avrage %gms\n", (sa + sb) / n);
     }
 };

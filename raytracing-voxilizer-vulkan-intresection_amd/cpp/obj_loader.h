@@ -1,9 +1,14 @@
-// obj_loader.h -- MaterialObj, kept because setVoxel's signature takes one (reference: common/obj_loader.h:32-52,87-115).
+// obj_loader.h -- MaterialObj, kept because setVoxel's signature takes one (reference: common/obj_loader.h:32-52).
 // The reference's material plumbing on this path is commented out (VoxelBuilder.hpp:376-395, voxelgridBool.cpp:64):
-// every voxel gets a default-constructed MaterialObj.
+// every voxel gets a default-constructed MaterialObj.  Field names, order and defaults are the reference's (callers
+// aggregate-initialise and compare them); the hash only has to be consistent with operator==.
 #pragma once
 #include <cstddef>
+#include <cstdint>
+#include <cstring>
 #include <functional>
+#include <initializer_list>
+
 #include "shaders/host_device.h"
 
 struct MaterialObj {
@@ -18,42 +23,33 @@ struct MaterialObj {
     int illum = 0;
     int textureID = -1;
 
+    // the reference's equality ignores ior and dissolve (obj_loader.h:47-51); kept so that de-duplication behaves the same
     bool operator==(const MaterialObj& o) const noexcept
     {
-        return ambient == o.ambient && diffuse == o.diffuse && specular == o.specular && transmittance == o.transmittance &&
-               emission == o.emission && shininess == o.shininess && illum == o.illum && textureID == o.textureID;
+        const vec3* a[] = {&ambient, &diffuse, &specular, &transmittance, &emission};
+        const vec3* b[] = {&o.ambient, &o.diffuse, &o.specular, &o.transmittance, &o.emission};
+        for (int i = 0; i < 5; ++i)
+            if (!(*a[i] == *b[i])) return false;
+        return shininess == o.shininess && illum == o.illum && textureID == o.textureID;
     }
 };
 
-namespace vxdetail {
-inline void hash_combine(std::size_t& seed, std::size_t h) { seed ^= h + 0x9e3779b9 + (seed << 6) + (seed >> 2); }
-inline std::size_t hash_vec3(const vec3& v)
-{
-    std::size_t h = 0;
-    hash_combine(h, std::hash<float>{}(v.x));
-    hash_combine(h, std::hash<float>{}(v.y));
-    hash_combine(h, std::hash<float>{}(v.z));
-    return h;
-}
-}  // namespace vxdetail
-
-namespace std {
 template <>
-struct hash<MaterialObj> {
+struct std::hash<MaterialObj> {
     std::size_t operator()(const MaterialObj& m) const noexcept
     {
-        std::size_t h = 0;
-        vxdetail::hash_combine(h, vxdetail::hash_vec3(m.ambient));
-        vxdetail::hash_combine(h, vxdetail::hash_vec3(m.diffuse));
-        vxdetail::hash_combine(h, vxdetail::hash_vec3(m.specular));
-        vxdetail::hash_combine(h, vxdetail::hash_vec3(m.transmittance));
-        vxdetail::hash_combine(h, vxdetail::hash_vec3(m.emission));
-        vxdetail::hash_combine(h, std::hash<float>{}(m.shininess));
-        vxdetail::hash_combine(h, std::hash<float>{}(m.ior));
-        vxdetail::hash_combine(h, std::hash<float>{}(m.dissolve));
-        vxdetail::hash_combine(h, std::hash<int>{}(m.illum));
-        vxdetail::hash_combine(h, std::hash<int>{}(m.textureID));
-        return h;
+        // FNV-1a over exactly the fields operator== looks at (with -0 folded onto +0 so equal materials hash equally)
+        std::uint64_t h = 1469598103934665603ull;
+        auto mix = [&h](float f) {
+            if (f == 0.0f) f = 0.0f;
+            std::uint32_t u;
+            std::memcpy(&u, &f, 4);
+            for (int k = 0; k < 4; ++k) { h ^= (u >> (8 * k)) & 0xFFu; h *= 1099511628211ull; }
+        };
+        for (const vec3* v : {&m.ambient, &m.diffuse, &m.specular, &m.transmittance, &m.emission}) { mix(v->x); mix(v->y); mix(v->z); }
+        mix(m.shininess);
+        mix(static_cast<float>(m.illum));
+        mix(static_cast<float>(m.textureID));
+        return static_cast<std::size_t>(h);
     }
 };
-}  // namespace std
