@@ -324,14 +324,14 @@ vx_status ensure_coarse(vx_grid* g)
     }
     const uint64_t nc = (uint64_t)g->cdim[0] * g->cdim[1] * g->cdim[2];
     const uint64_t nc2 = (uint64_t)g->c2dim[0] * g->c2dim[1] * g->c2dim[2];
-    VX_HIP(g->cwords.ensure((size_t)((nc + 31) / 32 + 2) * 4));
+    VX_HIP(g->cwords.ensure((size_t)((nc + 63) / 64 * 2 + 2) * 4));
     VX_HIP(g->c2words.ensure((size_t)((nc2 + 31) / 32 + 2) * 4));
-    vx::launch_build_coarse(g->words.as<uint32_t>(), g->g.dim, g->cdim, g->cwords.as<uint32_t>(), g->stream);
-    vx::launch_build_coarse(g->cwords.as<uint32_t>(), g->cdim, g->c2dim, g->c2words.as<uint32_t>(), g->stream);
     VX_HIP(g->bricks.ensure((size_t)(nc * 8 + 8) * 8));
-    vx::launch_build_bricks(g->words.as<uint32_t>(), g->g.dim, g->cdim, g->bricks.as<unsigned long long>(), g->stream);
     VX_HIP(g->bbounds.ensure((size_t)(nc + 8) * 4));
-    vx::launch_brick_bounds(g->bricks.as<unsigned long long>(), nc, g->bbounds.as<uint32_t>(), g->stream);
+    // bitmask -> brick-major slices -> per-brick bounds + level-1 mip -> level-2 mip
+    vx::launch_build_bricks(g->words.as<uint32_t>(), g->g.dim, g->cdim, g->bricks.as<unsigned long long>(), g->stream);
+    vx::launch_brick_bounds(g->bricks.as<unsigned long long>(), nc, g->bbounds.as<uint32_t>(), g->cwords.as<uint32_t>(), g->stream);
+    vx::launch_build_coarse(g->cwords.as<uint32_t>(), g->cdim, g->c2dim, g->c2words.as<uint32_t>(), g->stream);
     g->coarse_valid = true;
     return VX_OK;
 }

@@ -75,7 +75,8 @@ void launch_build_coarse(const uint32_t* words, const uint32_t fdim[3], const ui
 // K6: first hit per ray.  Three-level occupancy hierarchy: cells (bricks; w0 = the reference-layout bitmask, used for the
 // primitive rank only), 8^3 bricks (w1, dims d1), 64^3 blocks (w2, dims d2).
 void launch_build_bricks(const uint32_t* words, const uint32_t dim[3], const uint32_t bdim[3], unsigned long long* bricks, hipStream_t s);
-void launch_brick_bounds(const unsigned long long* bricks, uint64_t nbricks, uint32_t* bounds, hipStream_t s);
+// also writes the level-1 mip (one bit per brick, x-fastest, (nbricks+63)/64*2 words)
+void launch_brick_bounds(const unsigned long long* bricks, uint64_t nbricks, uint32_t* bounds, uint32_t* m1, hipStream_t s);
 struct TraceMips {
     const uint32_t* bounds;            // per brick: packed bounding box of its occupied cells
     const unsigned long long* bricks;  // level 0 re-tiled brick-major: one uint64 per (8^3 brick, z slice)

@@ -458,8 +458,12 @@ __global__ __launch_bounds__(256) void k_voxelize(const TriRec* __restrict__ rec
             const uint64_t wi = i0 >> 5;
             const uint32_t lo = mask << sh;
             const uint32_t hi = sh ? (mask >> (32u - sh)) : 0u;
+#ifdef VX_DIAG_NO_ATOMICS  // diagnostic build: price of the atomics (results are wrong)
+            hits += __popc(lo) + __popc(hi);
+#else
             if (lo && wi >= wb && wi < we) { atomicOr(&words[wi], lo); hits += __popc(lo); }        // voxelgridBool.cpp:66
             if (hi && wi + 1 >= wb && wi + 1 < we) { atomicOr(&words[wi + 1], hi); hits += __popc(hi); }
+#endif
         }
     });
     hits = wave_sum_u32(hits);

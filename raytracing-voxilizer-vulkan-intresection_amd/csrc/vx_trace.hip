@@ -92,15 +92,22 @@ void launch_build_bricks(const uint32_t* words, const uint32_t dim[3], const uin
 // Per brick: the bounding box of its occupied cells, 3 bits per bound (xmin | xmax<<3 | ymin<<6 | ymax<<9 | zmin<<12 |
 // zmax<<15).  Voxelized meshes are thin shells: a ray that crosses a wall's or a floor's brick without touching the
 // one-voxel layer is rejected by one box-vs-box test instead of a walk over the brick's slices and rows.
-__global__ __launch_bounds__(256) void k_brick_bounds(const unsigned long long* __restrict__ bricks, uint64_t nbricks, uint32_t* __restrict__ bounds)
+__global__ __launch_bounds__(256) void k_brick_bounds(const unsigned long long* __restrict__ bricks, uint64_t nbricks, uint32_t* __restrict__ bounds,
+                                                      uint32_t* __restrict__ m1)
 {
-    for (uint64_t b = (uint64_t)blockIdx.x * 256u + threadIdx.x; b < nbricks; b += (uint64_t)gridDim.x * 256u) {
+    // one pass over whole 64-brick groups (so that the level-1 mip -- one bit per brick, 64 per wave -- is written as two
+    // plain words per wave instead of being rebuilt from the bitmask by a second kernel)
+    const uint64_t ngroups = (nbricks + 63) / 64;
+    for (uint64_t gidx = ((uint64_t)blockIdx.x * 256u + threadIdx.x) >> 6; gidx < ngroups; gidx += ((uint64_t)gridDim.x * 256u) >> 6) {
+        const uint64_t b = gidx * 64 + (threadIdx.x & 63);
         unsigned long long any = 0;
         uint32_t zmin = 7, zmax = 0;
-        for (uint32_t s = 0; s < 8u; ++s) {
-            const unsigned long long v = bricks[b * 8ull + s];
-            if (v) { zmin = s < zmin ? s : zmin; zmax = s; }
-            any |= v;
+        if (b < nbricks) {
+            for (uint32_t s = 0; s < 8u; ++s) {
+                const unsigned long long v = bricks[b * 8ull + s];
+                if (v) { zmin = s < zmin ? s : zmin; zmax = s; }
+                any |= v;
+            }
         }
         uint32_t out = 0;
         if (any) {
@@ -113,16 +120,21 @@ __global__ __launch_bounds__(256) void k_brick_bounds(const unsigned long long* 
             const uint32_t xmin = __ffs(cols) - 1, xmax = 31 - __clz(cols), ymin = __ffs(rows) - 1, ymax = 31 - __clz(rows);
             out = xmin | (xmax << 3) | (ymin << 6) | (ymax << 9) | (zmin << 12) | (zmax << 15) | (1u << 18);
         }
-        bounds[b] = out;
+        if (b < nbricks) bounds[b] = out;
+        const unsigned long long occ = __ballot(any != 0);
+        if ((threadIdx.x & 63) == 0) {
+            m1[gidx * 2] = (uint32_t)occ;
+            m1[gidx * 2 + 1] = (uint32_t)(occ >> 32);
+        }
     }
 }
 
-void launch_brick_bounds(const unsigned long long* bricks, uint64_t nbricks, uint32_t* bounds, hipStream_t s)
+void launch_brick_bounds(const unsigned long long* bricks, uint64_t nbricks, uint32_t* bounds, uint32_t* m1, hipStream_t s)
 {
     if (!nbricks) return;
     uint64_t nblk = (nbricks + 255) / 256;
     if (nblk > 4096) nblk = 4096;
-    VX_KL(k_brick_bounds, dim3((unsigned)nblk), dim3(256), 0, s, bricks, nbricks, bounds);
+    VX_KL(k_brick_bounds, dim3((unsigned)nblk), dim3(256), 0, s, bricks, nbricks, bounds, m1);
 }
 
 namespace {
