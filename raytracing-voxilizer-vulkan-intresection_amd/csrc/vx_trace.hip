@@ -528,8 +528,11 @@ __device__ __forceinline__ unsigned long long pack_key(float t, unsigned long lo
 //                   independently (every cell overlapping the slice, with the usual probes); results meet in a 64-bit
 //                   atomicMin of (t bits << 32 | voxel index) -- the same "closest, then lower index" order the
 //                   single-walk uses.  k_merge then writes the spilled rays' outputs.
+#ifndef VX_TRACE_OCC
+#define VX_TRACE_OCC 1
+#endif
 template <bool LDS_M1, bool SEGMENTS>
-__global__ __launch_bounds__(256) void k_trace(GridParams g, TraceMips M, const float* __restrict__ rays, const Camera* __restrict__ cam, uint64_t nrays,
+__global__ __launch_bounds__(256, VX_TRACE_OCC) void k_trace(GridParams g, TraceMips M, const float* __restrict__ rays, const Camera* __restrict__ cam, uint64_t nrays,
                                                float tmin,
                                                float tmax, const float* __restrict__ tmax_per_ray, int any_hit, float* __restrict__ t_out,
                                                unsigned long long* __restrict__ idx_out, uint8_t* __restrict__ shadowed_out,

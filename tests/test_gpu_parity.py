@@ -455,3 +455,29 @@ def test_primary_rays_with_normals(gpu):
     assert np.array_equal(out["t"] > 0, ref["t"] > 0) and np.allclose(out["t"], ref["t"], rtol=0, atol=1e-5)
     same = out["prim"] == ref["prim"]
     assert same.mean() > 0.999 and np.array_equal(out["normal"][same], ref["normal"][same])
+
+
+def test_c4_atrium_1024_eight_shards(gpu):
+    """BASELINE configs[3] on one device: the atrium at exactly 1024^3, voxelized as 8 word-aligned shards (what the 8 ranks
+    of a node do) -- shards are word-disjoint, their union equals the unsharded mask, and that mask equals the oracle's."""
+    v, t = vx_scenes.scene("atrium262k")
+    vs = np.float32(32.0 / 1024)
+    mesh = gpu.Mesh.from_arrays(v, t)
+    full = gpu.Grid.voxelize(mesh, vs)
+    d = full.describe()
+    assert d["dim"] == (1024, 1024, 1024)
+    fw = full.bitmask()
+    ow, calls, gi = oracle.build_bool(v, t, vs, threads=16)
+    assert np.array_equal(fw, ow) and d["set_calls"] == calls
+    acc = np.zeros_like(fw)
+    total_calls = 0
+    g = None
+    for r in range(8):
+        b, e, chunk = gpu.shard_words(fw.size, r, 8)
+        g = gpu.Grid.voxelize(mesh, vs, words=(b, e))
+        w = g.bitmask()
+        assert not (acc & w).any()                      # disjoint supports: all-gather == OR == sum
+        acc |= w
+        total_calls += g.describe()["set_calls"]
+    assert np.array_equal(acc, fw)
+    assert total_calls >= calls                         # hits of words split between two shards are counted by both owners' halves only once each
