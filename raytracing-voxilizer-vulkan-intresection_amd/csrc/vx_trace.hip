@@ -516,6 +516,27 @@ struct __attribute__((aligned(16))) Spill {
 };
 static_assert(sizeof(Spill) == 32, "Spill must be 32 bytes");
 
+// position of the n-th (0-based) set bit of a 64-bit mask (n < popcount)
+__device__ __forceinline__ int nth_set_bit64(unsigned long long m, int n)
+{
+    int pos = 0;
+    unsigned lo = (unsigned)m;
+    int c = __popc(lo);
+    if (n >= c) { n -= c; pos = 32; lo = (unsigned)(m >> 32); }
+    c = __popc(lo & 0xFFFFu); if (n >= c) { n -= c; pos += 16; lo >>= 16; }
+    c = __popc(lo & 0xFFu);   if (n >= c) { n -= c; pos += 8;  lo >>= 8; }
+    c = __popc(lo & 0xFu);    if (n >= c) { n -= c; pos += 4;  lo >>= 4; }
+    c = __popc(lo & 0x3u);    if (n >= c) { n -= c; pos += 2;  lo >>= 2; }
+    c = lo & 1u;              if (n >= c) { pos += 1; }
+    return pos;
+}
+
+__device__ __forceinline__ float shfl_f(float v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int src)
+{
+    return ((unsigned long long)__shfl((unsigned)(v >> 32), src, 64) << 32) | __shfl((unsigned)v, src, 64);
+}
+
 __device__ __forceinline__ unsigned long long pack_key(float t, unsigned long long idx) { return ((unsigned long long)__float_as_uint(t) << 32) | (uint32_t)idx; }
 
 // Persistent waves with dynamic work fetch.  Exit condition every wave reaches: the work counter passes the item count (no
@@ -537,8 +558,9 @@ __global__ __launch_bounds__(256, VX_TRACE_OCC) void k_trace(GridParams g, Trace
                                                float tmax, const float* __restrict__ tmax_per_ray, int any_hit, float* __restrict__ t_out,
                                                unsigned long long* __restrict__ idx_out, uint8_t* __restrict__ shadowed_out,
                                                unsigned long long* next_item, Spill* __restrict__ spill, unsigned long long* nspill,
-                                               unsigned long long* __restrict__ keys, int budget, int nseg, uint32_t m1_words)
+                                               unsigned long long* __restrict__ keys, int budget, int nseg, uint32_t m1_words, uint32_t* __restrict__ donate_list)
 {
+    constexpr int kDonateBelow = 48;    // drain phase: donate work while at most this many lanes are busy
     // tuned on the bench workload (tools/trace_sweep.sh); the kernel is insensitive to them within +-5 %
     constexpr int kStepsPerRound = 4;   // upper-level steps between two brick-test phases
     constexpr int kItersPerRound = 2;   // (walk, brick test) iterations between two refill checks
@@ -561,6 +583,7 @@ __global__ __launch_bounds__(256, VX_TRACE_OCC) void k_trace(GridParams g, Trace
     const uint64_t kChunk = (uint64_t)kChunkRays;  // items a wave reserves per touch of the global counter
     uint64_t chunk_cur = 0, chunk_end = 0;
     int steps_left = 0;      // step budget of the current item
+    bool shared = false;     // this lane walks a PIECE of a split ray: its result goes through the ray's atomicMin key
 #ifdef VX_TRACE_DEBUG_CYCLES
     unsigned long long dbg_t0 = 0;
 #endif
@@ -606,6 +629,7 @@ __global__ __launch_bounds__(256, VX_TRACE_OCC) void k_trace(GridParams g, Trace
                     } else {
                         r = mine;
                     }
+                    shared = false;
                     load_ray(primary, r, rays, cam, R.ox, R.oy, R.oz, R.dx, R.dy, R.dz);
                     const float tmax_r = tmax_per_ray ? tmax_per_ray[r] : tmax;
                     R.tmax = tmax_r;
@@ -634,6 +658,60 @@ __global__ __launch_bounds__(256, VX_TRACE_OCC) void k_trace(GridParams g, Trace
         if (!__ballot(busy)) {
             if (drained) break;
             continue;
+        }
+        // ---- work donation (drain phase).  With 4 rays per lane at 1M rays the queue empties early and every wave is left
+        // with a few dozen long rays on a shrinking set of lanes.  Once no new ray can be fetched, a busy lane with enough of
+        // its t interval left hands the FAR half to an idle lane of its wave (ray and interval travel by shuffles); the two
+        // pieces are walked independently and meet in the atomicMin key of the ray, like the segment pass's slices.
+        if (!SEGMENTS && donate_list && drained) {
+            const unsigned long long bm = __ballot(busy);
+            const int nb = __popcll(bm);
+            if (nb <= kDonateBelow) {
+                const float t_cur = fmaxf(R.t_in, R.tn), t_end = fminf(R.tf, R.best + R.tau_term);
+                const float brick_time = 8.0f * g.vs / fmaxf(fmaxf(fabsf(R.dx), fabsf(R.dy)), fabsf(R.dz));
+                const bool can = busy && !R.pending && (t_end - t_cur > 6.0f * brick_time);
+                const unsigned long long dm = __ballot(can);
+                const unsigned long long im = ~bm;
+                const int ndon = min(__popcll(dm), 64 - nb);
+                if (ndon > 0) {
+                    // donor side: am I among the first ndon donors?
+                    const int drank = __popcll(dm & ((1ull << lane) - 1ull));
+                    const bool donor = can && drank < ndon;
+                    const float t_mid = 0.5f * (t_cur + t_end);
+                    // first split of a ray: remember it for k_merge
+                    const bool first = donor && !shared;
+                    const unsigned long long fm = __ballot(first);
+                    unsigned long long lb = 0;
+                    if (fm) {
+                        if (lane == 0) lb = atomicAdd(nspill, (unsigned long long)__popcll(fm));
+                        lb = shfl_u64(lb, 0);
+                        if (first) donate_list[lb + __popcll(fm & ((1ull << lane) - 1ull))] = (uint32_t)r;
+                    }
+                    // receiver side: the q-th idle lane takes the q-th donor's far half
+                    const int irank = __popcll(im & ((1ull << lane) - 1ull));
+                    const bool recv = !busy && irank < ndon;
+                    const int src = nth_set_bit64(dm, recv ? irank : 0);
+                    const float s_ox = shfl_f(R.ox, src), s_oy = shfl_f(R.oy, src), s_oz = shfl_f(R.oz, src);
+                    const float s_dx = shfl_f(R.dx, src), s_dy = shfl_f(R.dy, src), s_dz = shfl_f(R.dz, src);
+                    const float s_tmax = shfl_f(R.tmax, src), s_mid = shfl_f(t_mid, src), s_end = shfl_f(t_end, src), s_best = shfl_f(R.best, src);
+                    const unsigned long long s_bidx = shfl_u64(R.best_idx, src), s_r = shfl_u64(r, src);
+                    if (donor) {
+                        R.tf = t_mid;  // keep the near half (the walk ends with the cell that contains t_mid)
+                        shared = true;
+                    }
+                    if (recv) {
+                        r = s_r;
+                        R.ox = s_ox; R.oy = s_oy; R.oz = s_oz; R.dx = s_dx; R.dy = s_dy; R.dz = s_dz;
+                        R.tmax = s_tmax;
+                        busy = setup_ray(R, g, M, inv_vs, s_tmax, s_mid, s_end);
+                        R.best = s_best;
+                        R.best_idx = s_bidx;
+                        shared = true;
+                        steps_left = 1 << 20;
+                        if (!busy) r = ~0ull;
+                    }
+                }
+            }
         }
         // ---- trace, in two phases so that the wave's lanes run the same code together:
         // (1) upper-level walk until the lane has an occupied brick pending (or its ray is finished / out of budget),
@@ -689,7 +767,7 @@ __global__ __launch_bounds__(256, VX_TRACE_OCC) void k_trace(GridParams g, Trace
         // ---- retire: t and the voxel index of the hit; the primitive rank (two dependent loads), the normal and the hit
         // compaction are done by k_rank over all rays afterwards, off this kernel's critical path
         if (finished) {
-            if (SEGMENTS) {
+            if (SEGMENTS || shared) {
                 if (R.best_idx != ~0ull) atomicMin(&keys[r], pack_key(R.best, R.best_idx));
             } else {
                 float best_t = R.best_idx != ~0ull ? R.best : -1.0f;
@@ -706,6 +784,21 @@ __global__ __launch_bounds__(256, VX_TRACE_OCC) void k_trace(GridParams g, Trace
             busy = false;
             r = ~0ull;
         }
+    }
+}
+
+// outputs of the rays that were split by work donation, from their merged keys
+__global__ __launch_bounds__(256) void k_merge_list(const uint32_t* __restrict__ list, const unsigned long long* __restrict__ nlist,
+                                                    const unsigned long long* __restrict__ keys, float* __restrict__ t_out,
+                                                    unsigned long long* __restrict__ idx_out, uint8_t* __restrict__ shadowed_out)
+{
+    const unsigned long long n = *nlist;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256u) {
+        const uint32_t r = list[i];
+        const unsigned long long k = keys[r];
+        if (t_out) t_out[r] = k == ~0ull ? -1.0f : __uint_as_float((uint32_t)(k >> 32));
+        if (idx_out) idx_out[r] = k == ~0ull ? ~0ull : (k & 0xFFFFFFFFull);
+        if (shadowed_out) shadowed_out[r] = k == ~0ull ? 0 : 1;
     }
 }
 
@@ -810,18 +903,26 @@ void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* wo
     unsigned long long* idx_out = want_rank ? idx_tmp : nullptr;
     const size_t shmem = lds_m1 ? (size_t)m1_words * 4 : 0;
     // ray splitting needs the voxel index in 32 bits of the merge key and rays numbered in 32 bits
-    const bool split = env_budget > 0 && env_nseg > 1 && spill_buf && keys && g.nvox <= 0x100000000ull && nrays < 0xFFFFFFFFull;
+    const bool mergeable = spill_buf && keys && g.nvox <= 0x100000000ull && nrays < 0xFFFFFFFFull;
+    const bool split = env_budget > 0 && env_nseg > 1 && mergeable;
     Spill* sp = split ? (Spill*)spill_buf : nullptr;
     const int budget = split ? env_budget : 0;
+    // intra-wave work donation in the drain phase (default on; VOXHIP_TRACE_DONATE=0 disables); it shares the ray list /
+    // key machinery with the budget split, so the two are not combined
+    static const int env_donate = getenv("VOXHIP_TRACE_DONATE") ? atoi(getenv("VOXHIP_TRACE_DONATE")) : 1;
+    const bool donate = env_donate && mergeable && !split;
+    uint32_t* dlist = donate ? (uint32_t*)spill_buf : nullptr;
+    if (donate) (void)hipMemsetAsync(keys, 0xFF, (size_t)nrays * 8, s);  // "no hit" in every ray's merge key
 #define VX_LAUNCH(L, SEG, GRID, CNT)                                                                                                             \
     VX_KL((k_trace<L, SEG>), GRID, block, shmem, s, g, mips, io.rays, c, nrays, io.tmin, io.tmax, io.tmax_per_ray, io.any_hit ? 1 : 0, io.t_out, idx_out, \
-          io.shadowed_out, CNT, sp, counters + 1, keys, budget, env_nseg, m1_words)
+          io.shadowed_out, CNT, sp, counters + 1, keys, budget, env_nseg, m1_words, dlist)
     if (lds_m1) VX_LAUNCH(true, false, grid, counters); else VX_LAUNCH(false, false, grid, counters);
     if (split) {
         const dim3 sgrid((unsigned)env_blocks);
         if (lds_m1) VX_LAUNCH(true, true, sgrid, counters + 2); else VX_LAUNCH(false, true, sgrid, counters + 2);
         VX_KL(k_merge, dim3(256), block, 0, s, sp, counters + 1, keys, io.t_out, idx_out, io.shadowed_out);
     }
+    if (donate) VX_KL(k_merge_list, dim3(256), block, 0, s, dlist, counters + 1, keys, io.t_out, idx_out, io.shadowed_out);
 #undef VX_LAUNCH
     if (want_rank) {
         if (io.hits && io.nhits) (void)hipMemsetAsync(io.nhits, 0, sizeof(unsigned long long), s);
