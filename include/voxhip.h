@@ -192,6 +192,9 @@ vx_status vx_trace_ex(const vx_grid* g, const vx_trace_args* args);
 /* ---- measurement aid: per-kernel durations from HIP events recorded on the launch stream (off by default).
  * slot = 0,1,... until VX_ERR_INVALID_ARG; name is the kernel symbol as launched. */
 vx_status vx_profile_enable(int on);
+/* time only launches of this kernel (bare name, e.g. "k_trace"); NULL or "" = every kernel.  Two event records per
+ * launch are not free, so a throughput measurement selects the one kernel it prices. */
+vx_status vx_profile_select(const char* kernel_name);
 vx_status vx_profile_reset(void);
 vx_status vx_profile_read(int slot, char* name, size_t name_capacity, double* total_ms, uint64_t* launches);
 

@@ -43,6 +43,11 @@ def build_lib(force=False, verbose=False):
     os.makedirs(objdir, exist_ok=True)
     hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
     objs = []
+    # a change of flags (diagnostic -D builds) invalidates every object
+    stamp = os.path.join(objdir, "flags.txt")
+    flags_now = " ".join(FLAGS)
+    if not os.path.exists(stamp) or open(stamp).read() != flags_now:
+        force = True
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
         obj = os.path.join(objdir, src + ".o")
@@ -54,6 +59,8 @@ def build_lib(force=False, verbose=False):
             _run(cmd)
     if force or _newer(LIB, objs):
         _run([HIPCC, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs)
+    with open(stamp, "w") as fh:
+        fh.write(flags_now)
     return LIB
 
 

@@ -1069,6 +1069,11 @@ vx_status vx_profile_enable(int on)
     vx::prof_enable(on != 0);
     return VX_OK;
 }
+vx_status vx_profile_select(const char* kernel_name)
+{
+    vx::prof_select(kernel_name);
+    return VX_OK;
+}
 vx_status vx_profile_reset(void)
 {
     vx::prof_reset();

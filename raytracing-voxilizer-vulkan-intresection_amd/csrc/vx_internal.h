@@ -27,6 +27,7 @@ struct Camera { float viewInv[16]; float projInv[16]; uint32_t width, height; };
 
 // ---- optional per-kernel event timing (vx_prof.cpp) ----------------------------------------------------------
 void prof_enable(bool on);
+void prof_select(const char* name);  // nullptr/"" = all kernels
 bool prof_enabled();
 void prof_reset();
 int prof_read(int slot, char* name, size_t cap, double* ms, uint64_t* n);

@@ -14,6 +14,7 @@ struct Pending { const char* name; hipEvent_t a, b; };
 struct Acc { double ms = 0.0; uint64_t n = 0; };
 std::mutex g_mu;
 bool g_on = false;
+std::string g_only;  // when set, only launches of this kernel are timed (two events per launch are not free)
 std::vector<Pending> g_pending;
 std::vector<hipEvent_t> g_free;
 std::map<std::string, Acc> g_acc;
@@ -44,12 +45,21 @@ void collect_locked()
 
 void prof_enable(bool on) { std::lock_guard<std::mutex> lk(g_mu); g_on = on; }
 bool prof_enabled() { return g_on; }
+void prof_select(const char* name) { std::lock_guard<std::mutex> lk(g_mu); g_only = name ? name : ""; }
 void prof_reset() { std::lock_guard<std::mutex> lk(g_mu); collect_locked(); g_acc.clear(); }
 
 ProfScope::ProfScope(const char* name, hipStream_t s) : name_(name), s_(s), a_(nullptr)
 {
     if (!g_on) return;
     std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_only.empty()) {
+        // launched names look like "k_scan_sums" or "(k_trace<L, SEG>)": compare the bare kernel name
+        const char* q = name;
+        while (*q == '(') ++q;
+        size_t n = 0;
+        while (q[n] && q[n] != '<' && q[n] != ')') ++n;
+        if (g_only.size() != n || g_only.compare(0, n, q, n) != 0) return;
+    }
     a_ = get_event();
     if (a_) (void)hipEventRecord(a_, s_);
 }

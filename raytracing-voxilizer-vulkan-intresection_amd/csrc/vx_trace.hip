@@ -33,7 +33,9 @@
 // No MFMA: this is traversal, not a contraction.  Algorithmic HBM traffic is the ray stream (24 B in, 4-8 B out per ray).
 #include "vx_internal.h"
 
+#include <cstddef>
 #include <cstdlib>
+#include <cstring>
 
 #pragma clang fp contract(off)
 
@@ -449,72 +451,65 @@ __device__ __forceinline__ bool upper_step(Lane& R, const GridParams& g, const T
         }
         if (R.todo) return true;  // more cells to look at; otherwise finish the cell right away
     }
-    if (lvl == 2 && R.occ) {
-        // descend into the NOMINAL block's bricks, starting exactly at its entry time (a time slack would slide the
-        // start point along the ray's major axis; the start cell's rounding is covered by the brick walk's probes)
-        R.px = R.cx; R.py = R.cy; R.pz = R.cz;
-        const int lx = R.cx * 8, ly = R.cy * 8, lz = R.cz * 8;
-        enter_level(R, g, inv_vs, 3, lx, ly, lz, lx + 8, ly + 8, lz + 8, fmaxf(R.t_in, R.tn));
-        R.lvl = 1;
-        R.fresh = true;
-        R.occ = false;
-        return true;
-    }
+    // ---- finish the cell: descend (level 2, something found), terminate, advance, or leave the block (level 1).
+    // All three moves end in "new cell at some level": its six plane times are recomputed from the cell index (plane_t is a
+    // pure function of the index, so the recomputed values are the ones an incremental update would carry).  One shared tail
+    // instead of three code paths: the wave pays for the union of its lanes' paths at every step.
+    const bool desc = lvl == 2 && R.occ;
     // Termination.  Every cell not looked at yet has slab t0 >= t_o - tau(major axis): along the major axis the ray is
     // monotone and well conditioned, so cells of later major-axis slabs are entered no earlier than t_o - tau_major; cells of
     // the current slab that are reached through another axis were either flagged as near-ties and looked at just now, or
     // their crossing is more than the tolerance away.  (The sum of all three taus is NOT needed: one tiny direction
     // component would make it infinite and force those rays through the whole grid -- the tail of the kernel.)
-    const float lim = fminf(R.tf, R.best + R.tau_term);
-    if (!(t_o <= lim)) return false;
-    // advance along the exit axis (branch-free: select the axis' operands, compute once, write back)
-    const int sh = lvl * 3;
-    const float tau_exit_adv = sel3(ex, ey, R.taux, R.tauy, R.tauz);
-    const float org_a = sel3(ex, ey, g.org[0], g.org[1], g.org[2]);
-    const float o_a = sel3(ex, ey, R.ox, R.oy, R.oz);
-    const float i_a = sel3(ex, ey, R.ix, R.iy, R.iz);
-    const int s_a = sel3(ex, ey, sx, sy, sz);
-    const int c_a = sel3(ex, ey, R.cx, R.cy, R.cz) + s_a;
-    const int p_a = sel3(ex, ey, R.px, R.py, R.pz);
-    const int top_hi = sel3(ex, ey, (int)M.d2[0], (int)M.d2[1], (int)M.d2[2]) + 1;
-    const int lo_a = lvl == 2 ? -1 : p_a * 8;
-    const int hi_a = lvl == 2 ? top_hi : p_a * 8 + 8;
-    const bool out = c_a < lo_a || c_a >= hi_a;
-    const float tM_new = plane_t(org_a, g.vs, o_a, i_a, (c_a + (s_a > 0 ? 1 : 0)) * (1 << sh));
-    if (ex) { R.cx = c_a; R.tPx = R.tMx; R.tMx = tM_new; }
-    else if (ey) { R.cy = c_a; R.tPy = R.tMy; R.tMy = tM_new; }
-    else { R.cz = c_a; R.tPz = R.tMz; R.tMz = tM_new; }
-    R.emask = ex ? 1 : (ey ? 2 : 4);
-    R.tau_ent = tau_exit_adv;
-    R.t_in = t_o;
-    R.fresh = true;
-    if (out) {
-        // left the block: resume the block level (its plane times are recomputed, not stored); the block itself has been
-        // visited already, so it only advances on the next step
-        if (lvl == 2) return false;
-        R.cx = R.px; R.cy = R.py; R.cz = R.pz;
-        axis_planes(R.tMx, R.tPx, R.cx, R.ox, R.dx, R.ix, g.org[0], g.vs, 6);
-        axis_planes(R.tMy, R.tPy, R.cy, R.oy, R.dy, R.iy, g.org[1], g.vs, 6);
-        axis_planes(R.tMz, R.tPz, R.cz, R.oz, R.dz, R.iz, g.org[2], g.vs, 6);
-        R.lvl = 2;
-        R.fresh = false;
-        R.todo = 0u;
-        R.occ = false;
+    if (!desc && !(t_o <= fminf(R.tf, R.best + R.tau_term))) return false;
+    int ncx = R.cx, ncy = R.cy, ncz = R.cz, nl = lvl;
+    float t_new = t_o;
+    bool pop = false;
+    if (desc) {
+        // into the NOMINAL block's bricks, starting exactly at its entry time (a time slack would slide the start point
+        // along the ray's major axis; the start cell's rounding is covered by the brick walk's probes)
+        R.px = R.cx; R.py = R.cy; R.pz = R.cz;
+        t_new = fmaxf(R.t_in, R.tn);
+        const int lx = R.cx * 8, ly = R.cy * 8, lz = R.cz * 8;
+        ncx = start_cell(R.ox, R.dx, g.org[0], inv_vs, 3, lx, lx + 8, t_new);
+        ncy = start_cell(R.oy, R.dy, g.org[1], inv_vs, 3, ly, ly + 8, t_new);
+        ncz = start_cell(R.oz, R.dz, g.org[2], inv_vs, 3, lz, lz + 8, t_new);
+        nl = 1;
+    } else {
+        const int s_a = sel3(ex, ey, sx, sy, sz);
+        const int c_a = sel3(ex, ey, R.cx, R.cy, R.cz) + s_a;
+        const int p_a = sel3(ex, ey, R.px, R.py, R.pz);
+        const int top_hi = sel3(ex, ey, (int)M.d2[0], (int)M.d2[1], (int)M.d2[2]) + 1;
+        const int lo_a = lvl == 2 ? -1 : p_a * 8;
+        const int hi_a = lvl == 2 ? top_hi : p_a * 8 + 8;
+        if (c_a < lo_a || c_a >= hi_a) {
+            if (lvl == 2) return false;  // left the grid (and its halo)
+            // left the block: back to the block level; the block itself has been visited, it only advances next
+            pop = true;
+            ncx = R.px; ncy = R.py; ncz = R.pz;
+            nl = 2;
+        } else {
+            ncx = ex ? c_a : ncx;
+            ncy = ey ? c_a : ncy;
+            ncz = (!ex && !ey) ? c_a : ncz;
+        }
     }
+    const int sh = nl * 3;
+    R.cx = ncx; R.cy = ncy; R.cz = ncz;
+    R.lvl = nl;
+    axis_planes(R.tMx, R.tPx, ncx, R.ox, R.dx, R.ix, g.org[0], g.vs, sh);
+    axis_planes(R.tMy, R.tPy, ncy, R.oy, R.dy, R.iy, g.org[1], g.vs, sh);
+    axis_planes(R.tMz, R.tPz, ncz, R.oz, R.dz, R.iz, g.org[2], g.vs, sh);
+    R.t_in = t_new;
+    R.emask = desc ? 0 : (ex ? 1 : (ey ? 2 : 4));
+    R.tau_ent = desc ? 0.0f : sel3(ex, ey, R.taux, R.tauy, R.tauz);
+    R.fresh = !pop;
+    R.todo = 0u;
+    R.occ = false;
     return true;
 }
 
 }  // namespace
-
-// One spilled ray: the main pass gave up on it after its step budget; [t0, tf] is what is left to walk.
-struct __attribute__((aligned(16))) Spill {
-    uint32_t ray;
-    float t0, tf;          // restart time (entry of the cell it was in), end of the useful interval
-    float best;            // best accepted t so far (+inf: none)
-    unsigned long long best_idx;
-    unsigned long long pad;
-};
-static_assert(sizeof(Spill) == 32, "Spill must be 32 bytes");
 
 // position of the n-th (0-based) set bit of a 64-bit mask (n < popcount)
 __device__ __forceinline__ int nth_set_bit64(unsigned long long m, int n)
@@ -539,51 +534,95 @@ __device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int
 
 __device__ __forceinline__ unsigned long long pack_key(float t, unsigned long long idx) { return ((unsigned long long)__float_as_uint(t) << 32) | (uint32_t)idx; }
 
-// Persistent waves with dynamic work fetch.  Exit condition every wave reaches: the work counter passes the item count (no
-// refill possible) and every lane's item has finished; each item finishes in a bounded number of steps.
-//
-// Two passes of the same kernel bound the serial chain of a single ray (on 1M incoherent rays the kernel time WAS the
-// longest ray: ~270 steps at ~2.8 us, with 4 waves sharing a SIMD's issue):
-//   SEGMENTS=false  work item = ray.  A ray that exceeds `budget` steps is SPILLED: its remaining interval goes to a list.
-//   SEGMENTS=true   work item = (spilled ray, k of nseg): the k-th equal slice of the remaining t interval, walked
-//                   independently (every cell overlapping the slice, with the usual probes); results meet in a 64-bit
-//                   atomicMin of (t bits << 32 | voxel index) -- the same "closest, then lower index" order the
-//                   single-walk uses.  k_merge then writes the spilled rays' outputs.
-#ifndef VX_TRACE_OCC
-#define VX_TRACE_OCC 1
-#endif
-template <bool LDS_M1, bool SEGMENTS>
-__global__ __launch_bounds__(256, VX_TRACE_OCC) void k_trace(GridParams g, TraceMips M, const float* __restrict__ rays, const Camera* __restrict__ cam, uint64_t nrays,
-                                               float tmin,
-                                               float tmax, const float* __restrict__ tmax_per_ray, int any_hit, float* __restrict__ t_out,
-                                               unsigned long long* __restrict__ idx_out, uint8_t* __restrict__ shadowed_out,
-                                               unsigned long long* next_item, Spill* __restrict__ spill, unsigned long long* nspill,
-                                               unsigned long long* __restrict__ keys, int budget, int nseg, uint32_t m1_words, uint32_t* __restrict__ donate_list)
+// Everything the kernel is given, as ONE by-value argument.  The walk needs ~25 uniform values in scalar registers at every
+// step; the other ~35 dwords (ray source, outputs, work counters) are touched once per refill / retire.  Held as ordinary
+// kernel arguments they all stay live in SGPRs for the whole kernel and are spilled to VGPR lanes and read back
+// (v_readlane: 16 % of the kernel's vector instructions).  The cold block is therefore read from the kernarg segment where
+// it is used (scalar loads through a laundered pointer, which the compiler cannot hoist out of the loop).
+struct TraceHot {
+    GridParams g;
+    TraceMips M;
+    float tmin;
+    int any_hit;
+    uint32_t m1_words;
+    uint32_t pad;
+};
+struct TraceCold {
+    const float* rays;            // null: primary rays from *cam
+    const Camera* cam;
+    const float* tmax_per_ray;    // null: tmax
+    float tmax;
+    uint32_t pad;
+    uint64_t nrays;
+    float* t_out;
+    unsigned long long* idx_out;
+    uint8_t* shadowed_out;
+    unsigned long long* next_item;   // work counter
+    unsigned long long* nsplit;      // number of rays in split_list
+    unsigned long long* keys;        // per ray: atomicMin merge key of the pieces of a split ray
+    uint32_t* split_list;            // null: no work donation
+};
+struct TraceParams {
+    TraceHot hot;
+    TraceCold cold;
+};
+
+typedef const TraceCold __attribute__((address_space(4)))* ColdPtr;
+__device__ __forceinline__ ColdPtr cold_params()
 {
-    constexpr int kDonateBelow = 48;    // drain phase: donate work while at most this many lanes are busy
-    // tuned on the bench workload (tools/trace_sweep.sh); the kernel is insensitive to them within +-5 %
+    const char __attribute__((address_space(4)))* p = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return (ColdPtr)(p + offsetof(TraceParams, cold));
+}
+
+#ifdef VX_TRACE_DEBUG_UTIL
+// diagnostic build: where the wave cycles go.  [0..4] cycles in refill / donate / walk / brick test / retire,
+// [5] walk iterations, [6] sum of active lanes over them, [7] brick phases, [8] sum of lanes with a pending brick,
+// [9] rounds, [10] sum of busy lanes at round start
+__device__ unsigned long long g_trace_util[16];
+#define VX_UTIL_T(i) { const unsigned long long now_ = __builtin_readcyclecounter(); dbg_c[i] += now_ - dbg_last; dbg_last = now_; }
+#define VX_UTIL_ADD(i, v) dbg_c[i] += (unsigned long long)(v);
+#else
+#define VX_UTIL_T(i)
+#define VX_UTIL_ADD(i, v)
+#endif
+
+// Persistent waves with dynamic work fetch.  Exit condition every wave reaches: the work counter passes the ray count (no
+// refill possible) and every lane's ray (or piece of a ray) has finished; each finishes in a bounded number of steps, and a
+// piece is only split while its t interval is longer than six bricks.
+template <bool LDS_M1>
+__global__ __launch_bounds__(256) void k_trace(const TraceParams P)
+{
     constexpr int kStepsPerRound = 4;   // upper-level steps between two brick-test phases
     constexpr int kItersPerRound = 2;   // (walk, brick test) iterations between two refill checks
     constexpr int kRefillBelow = 44;    // refill when fewer than this many lanes are busy
-    constexpr int kChunkRays = 64;      // items a wave reserves per touch of the global counter
+    constexpr int kChunkRays = 64;      // rays a wave reserves per touch of the global counter
+    constexpr int kDonateBelow = 48;    // drain phase: donate work while at most this many lanes are busy
+    constexpr float kDonateBricks = 6.0f;  // ... and only from pieces with more than this many bricks of t interval left
+    // (tools/trace_sweep.sh, tools/don_sweep.sh: the kernel is insensitive to all of them within +-5 %)
+    const GridParams& g = P.hot.g;
+    const TraceMips& M = P.hot.M;
     extern __shared__ __attribute__((aligned(16))) uint32_t m1_lds[];
     if (LDS_M1) {
-        for (uint32_t i = threadIdx.x; i < m1_words; i += 256u) m1_lds[i] = M.w1[i];
+        for (uint32_t i = threadIdx.x; i < P.hot.m1_words; i += 256u) m1_lds[i] = M.w1[i];
         __syncthreads();
     }
     const int lane = threadIdx.x & 63;
     const float inv_vs = 1.0f / g.vs;
-    const bool primary = rays == nullptr;
-    const uint64_t nitems = SEGMENTS ? *nspill * (uint64_t)nseg : nrays;
     Lane R;
     uint64_t r = ~0ull;      // ray this lane is tracing (~0: none)
     bool busy = false;       // traversal in progress
-    bool drained = false;    // no item left for this wave: the global counter and the wave's chunk are exhausted
-    bool drained_global = false;
-    const uint64_t kChunk = (uint64_t)kChunkRays;  // items a wave reserves per touch of the global counter
-    uint64_t chunk_cur = 0, chunk_end = 0;
-    int steps_left = 0;      // step budget of the current item
     bool shared = false;     // this lane walks a PIECE of a split ray: its result goes through the ray's atomicMin key
+    bool drained = false;    // no ray left for this wave: the global counter and the wave's chunk are exhausted
+    bool drained_global = false;
+    uint64_t chunk_cur = 0, chunk_end = 0;
+#ifdef VX_TRACE_DEBUG_STEPS
+    int dbg_steps = 0;
+#endif
+#ifdef VX_TRACE_DEBUG_UTIL
+    unsigned long long dbg_c[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long dbg_last = __builtin_readcyclecounter();
+#endif
 #ifdef VX_TRACE_DEBUG_CYCLES
     unsigned long long dbg_t0 = 0;
 #endif
@@ -591,7 +630,9 @@ __global__ __launch_bounds__(256, VX_TRACE_OCC) void k_trace(GridParams g, Trace
         const unsigned long long busy_mask = __ballot(busy);
         const int nbusy = __popcll(busy_mask);
         if (!drained && nbusy < kRefillBelow) {
-            // ---- refill idle lanes.  Item indices come from a per-wave chunk; the global counter is touched once per chunk.
+            // ---- refill idle lanes.  Ray indices come from a per-wave chunk; the global counter is touched once per chunk.
+            const ColdPtr C = cold_params();
+            const uint64_t nrays = C->nrays;
             const unsigned long long idle_mask = ~busy_mask;
             const uint64_t need = (uint64_t)(64 - nbusy);
             const uint64_t take = need < chunk_end - chunk_cur ? need : chunk_end - chunk_cur;
@@ -600,76 +641,68 @@ __global__ __launch_bounds__(256, VX_TRACE_OCC) void k_trace(GridParams g, Trace
             uint64_t second = 0;
             if (take < need) {
                 unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(next_item, (unsigned long long)kChunk);
-                base = ((unsigned long long)__shfl((unsigned)(base >> 32), 0, 64) << 32) | __shfl((unsigned)base, 0, 64);
+                if (lane == 0) base = atomicAdd(C->next_item, (unsigned long long)kChunkRays);
+                base = shfl_u64(base, 0);
                 second = base;
                 chunk_cur = base + (need - take);
-                chunk_end = base + kChunk;
-                if (chunk_end > nitems) chunk_end = nitems > base ? nitems : base;
+                chunk_end = base + (uint64_t)kChunkRays;
+                if (chunk_end > nrays) chunk_end = nrays > base ? nrays : base;
                 if (chunk_cur > chunk_end) chunk_cur = chunk_end;
-                if (base + kChunk >= nitems) drained_global = true;
+                if (base + (uint64_t)kChunkRays >= nrays) drained_global = true;
             }
             if (drained_global && chunk_cur >= chunk_end) drained = true;
             if (!busy) {
                 const uint64_t pos = (uint64_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
-                const uint64_t mine = pos < take ? first + pos : (take < need ? second + (pos - take) : nitems);
-                if (mine < nitems) {
-                    float seg_a = 0.0f, seg_b = INFINITY, best0 = INFINITY;
-                    unsigned long long bidx0 = ~0ull;
-                    bool skip = false;
-                    if (SEGMENTS) {
-                        const Spill e = spill[mine / (uint64_t)nseg];
-                        const int k = (int)(mine % (uint64_t)nseg);
-                        r = e.ray;
-                        const float span = e.tf - e.t0;
-                        seg_a = e.t0 + span * ((float)k / (float)nseg);
-                        seg_b = k == nseg - 1 ? e.tf : e.t0 + span * ((float)(k + 1) / (float)nseg);
-                        best0 = e.best;
-                        bidx0 = e.best_idx;
-                    } else {
-                        r = mine;
-                    }
+                const uint64_t mine = pos < take ? first + pos : (take < need ? second + (pos - take) : nrays);
+                if (mine < nrays) {
+                    r = mine;
                     shared = false;
-                    load_ray(primary, r, rays, cam, R.ox, R.oy, R.oz, R.dx, R.dy, R.dz);
-                    const float tmax_r = tmax_per_ray ? tmax_per_ray[r] : tmax;
+                    const float* rays = C->rays;
+                    load_ray(rays == nullptr, r, rays, C->cam, R.ox, R.oy, R.oz, R.dx, R.dy, R.dz);
+                    const float* tpr = C->tmax_per_ray;
+                    const float tmax_r = tpr ? tpr[r] : C->tmax;
                     R.tmax = tmax_r;
-                    busy = setup_ray(R, g, M, inv_vs, tmax_r, seg_a, seg_b);
-                    if (SEGMENTS) {
-                        R.best = best0;
-                        R.best_idx = bidx0;
-                        skip = best0 + R.tau_term < seg_a;  // a hit found before the spill already precedes this slice
-                        if (skip) busy = false;
-                    }
+                    busy = setup_ray(R, g, M, inv_vs, tmax_r, 0.0f, INFINITY);
 #ifdef VX_TRACE_DEBUG_CYCLES
                     dbg_t0 = wall_clock64();
 #endif
-                    steps_left = (!SEGMENTS && budget > 0) ? budget : (1 << 20);
-                    if (!busy) {  // cannot touch the grid / nothing to do: retire at once
-                        if (!SEGMENTS) {
-                            if (t_out) t_out[r] = -1.0f;
-                            if (idx_out) idx_out[r] = ~0ull;
-                            if (shadowed_out) shadowed_out[r] = 0;
-                        }
+#ifdef VX_TRACE_DEBUG_STEPS
+                    dbg_steps = 0;
+#endif
+                    if (!busy) {  // cannot touch the grid: retire at once
+                        float* t_out = C->t_out;
+                        unsigned long long* idx_out = C->idx_out;
+                        uint8_t* shadowed_out = C->shadowed_out;
+                        if (t_out) t_out[r] = -1.0f;
+                        if (idx_out) idx_out[r] = ~0ull;
+                        if (shadowed_out) shadowed_out[r] = 0;
                         r = ~0ull;
                     }
                 }
             }
         }
-        if (!__ballot(busy)) {
+        VX_UTIL_T(0)
+        const unsigned long long bm = __ballot(busy);
+        if (!bm) {
             if (drained) break;
             continue;
         }
+        VX_UTIL_ADD(9, 1)
+        VX_UTIL_ADD(10, __popcll(bm))
         // ---- work donation (drain phase).  With 4 rays per lane at 1M rays the queue empties early and every wave is left
         // with a few dozen long rays on a shrinking set of lanes.  Once no new ray can be fetched, a busy lane with enough of
         // its t interval left hands the FAR half to an idle lane of its wave (ray and interval travel by shuffles); the two
-        // pieces are walked independently and meet in the atomicMin key of the ray, like the segment pass's slices.
-        if (!SEGMENTS && donate_list && drained) {
-            const unsigned long long bm = __ballot(busy);
-            const int nb = __popcll(bm);
-            if (nb <= kDonateBelow) {
+        // pieces are walked independently (every cell overlapping the piece, with the usual probes) and meet in a 64-bit
+        // atomicMin of (t bits << 32 | voxel index) -- the same "closest, then lower index" order a single walk uses.
+        // k_merge_list then writes the outputs of the rays that were split.
+        if (drained && __popcll(bm) <= kDonateBelow) {
+            const ColdPtr C = cold_params();
+            uint32_t* split_list = C->split_list;
+            if (split_list) {
+                const int nb = __popcll(bm);
                 const float t_cur = fmaxf(R.t_in, R.tn), t_end = fminf(R.tf, R.best + R.tau_term);
                 const float brick_time = 8.0f * g.vs / fmaxf(fmaxf(fabsf(R.dx), fabsf(R.dy)), fabsf(R.dz));
-                const bool can = busy && !R.pending && (t_end - t_cur > 6.0f * brick_time);
+                const bool can = busy && !R.pending && (t_end - t_cur > kDonateBricks * brick_time);
                 const unsigned long long dm = __ballot(can);
                 const unsigned long long im = ~bm;
                 const int ndon = min(__popcll(dm), 64 - nb);
@@ -678,14 +711,14 @@ __global__ __launch_bounds__(256, VX_TRACE_OCC) void k_trace(GridParams g, Trace
                     const int drank = __popcll(dm & ((1ull << lane) - 1ull));
                     const bool donor = can && drank < ndon;
                     const float t_mid = 0.5f * (t_cur + t_end);
-                    // first split of a ray: remember it for k_merge
+                    // first split of a ray: remember it for k_merge_list
                     const bool first = donor && !shared;
                     const unsigned long long fm = __ballot(first);
-                    unsigned long long lb = 0;
                     if (fm) {
-                        if (lane == 0) lb = atomicAdd(nspill, (unsigned long long)__popcll(fm));
+                        unsigned long long lb = 0;
+                        if (lane == 0) lb = atomicAdd(C->nsplit, (unsigned long long)__popcll(fm));
                         lb = shfl_u64(lb, 0);
-                        if (first) donate_list[lb + __popcll(fm & ((1ull << lane) - 1ull))] = (uint32_t)r;
+                        if (first) split_list[lb + __popcll(fm & ((1ull << lane) - 1ull))] = (uint32_t)r;
                     }
                     // receiver side: the q-th idle lane takes the q-th donor's far half
                     const int irank = __popcll(im & ((1ull << lane) - 1ull));
@@ -707,85 +740,89 @@ __global__ __launch_bounds__(256, VX_TRACE_OCC) void k_trace(GridParams g, Trace
                         R.best = s_best;
                         R.best_idx = s_bidx;
                         shared = true;
-                        steps_left = 1 << 20;
                         if (!busy) r = ~0ull;
                     }
                 }
             }
         }
         // ---- trace, in two phases so that the wave's lanes run the same code together:
-        // (1) upper-level walk until the lane has an occupied brick pending (or its ray is finished / out of budget),
+        // (1) upper-level walk until the lane has an occupied brick pending (or its ray is finished),
         // (2) the brick test for every lane with a pending brick.
-        bool finished = false, over = false;
+        bool finished = false;
+        VX_UTIL_T(1)
         for (int it = 0; it < kItersPerRound; ++it) {
             for (int k = 0; k < kStepsPerRound; ++k) {
-                const bool go = busy && !finished && !over && !R.pending;
-                if (!__ballot(go)) break;
+                const bool go = busy && !finished && !R.pending;
+                const unsigned long long gm = __ballot(go);
+                if (!gm) break;
+                VX_UTIL_ADD(5, 1)
+                VX_UTIL_ADD(6, __popcll(gm))
                 if (go) {
                     if (!upper_step<LDS_M1>(R, g, M, m1_lds, inv_vs)) finished = true;
-                    else if (--steps_left <= 0) over = true;
+#ifdef VX_TRACE_DEBUG_STEPS
+                    ++dbg_steps;
+#endif
                 }
             }
             const bool pend = busy && R.pending;
-            if (!__ballot(pend)) break;  // every live lane finished its ray in this round
+            const unsigned long long pm = __ballot(pend);
+            VX_UTIL_T(2)
+            if (!pm) break;  // every live lane finished its ray in this round
+            VX_UTIL_ADD(7, 1)
+            VX_UTIL_ADD(8, __popcll(pm))
             if (pend) {
-                brick_test(R, g, M, inv_vs, R.tolp, R.bx, R.by, R.bz, tmin, R.tmax);
+                brick_test(R, g, M, inv_vs, R.tolp, R.bx, R.by, R.bz, P.hot.tmin, R.tmax);
                 R.pending = false;
                 // shadow query (gl_RayFlagsTerminateOnFirstHitEXT, raytrace2.rchit:108): any accepted hit ends the ray
-                if (any_hit && R.best_idx != ~0ull) finished = true;
+                if (P.hot.any_hit && R.best_idx != ~0ull) finished = true;
             }
+            VX_UTIL_T(3)
         }
-        if (over && !finished) {
-            if (SEGMENTS || !spill) {
-                over = false;  // segments (and runs without a spill list) have no budget: keep going
-                steps_left = 1 << 20;
-            }
-        }
-        // ---- spill (main pass): hand the rest of an over-budget ray to the segment pass
-        {
-            const bool sp = !SEGMENTS && over && !finished;
-            const unsigned long long sbal = __ballot(sp);
-            if (sbal) {
-                unsigned long long sb = 0;
-                if (lane == 0) sb = atomicAdd(nspill, (unsigned long long)__popcll(sbal));
-                sb = ((unsigned long long)__shfl((unsigned)(sb >> 32), 0, 64) << 32) | __shfl((unsigned)sb, 0, 64);
-                if (sp) {
-                    Spill e;
-                    e.ray = (uint32_t)r;
-                    e.t0 = fmaxf(R.t_in, R.tn);   // the cell it is in is walked again from its entry
-                    e.tf = fminf(R.tf, R.best + R.tau_term);
-                    e.best = R.best;
-                    e.best_idx = R.best_idx;
-                    e.pad = 0;
-                    spill[sb + __popcll(sbal & ((1ull << lane) - 1ull))] = e;
-                    keys[r] = R.best_idx != ~0ull ? pack_key(R.best, R.best_idx) : ~0ull;
-                    busy = false;
-                    r = ~0ull;
-                }
-            }
-        }
+        VX_UTIL_T(2)
         // ---- retire: t and the voxel index of the hit; the primitive rank (two dependent loads), the normal and the hit
         // compaction are done by k_rank over all rays afterwards, off this kernel's critical path
-        if (finished) {
-            if (SEGMENTS || shared) {
-                if (R.best_idx != ~0ull) atomicMin(&keys[r], pack_key(R.best, R.best_idx));
-            } else {
-                float best_t = R.best_idx != ~0ull ? R.best : -1.0f;
+        if (__ballot(finished)) {
+            const ColdPtr C = cold_params();
+            if (finished) {
+                if (shared) {
+                    if (R.best_idx != ~0ull) atomicMin(C->keys + r, pack_key(R.best, R.best_idx));
+                } else {
+                    float best_t = R.best_idx != ~0ull ? R.best : -1.0f;
 #ifdef VX_TRACE_DEBUG_CYCLES
-                best_t = (float)(wall_clock64() - dbg_t0);  // diagnostic build: report the ray's residency in 100 MHz ticks
+                    best_t = (float)(wall_clock64() - dbg_t0);  // diagnostic build: report the ray's residency in 100 MHz ticks
 #endif
 #ifdef VX_TRACE_DEBUG_STEPS
-                best_t = (float)((1 << 20) - steps_left);  // diagnostic build: report the step count instead of t
+                    best_t = (float)dbg_steps;  // diagnostic build: report the step count instead of t
 #endif
-                if (t_out) t_out[r] = best_t;
-                if (idx_out) idx_out[r] = R.best_idx;
-                if (shadowed_out) shadowed_out[r] = R.best_idx != ~0ull ? 1 : 0;
+                    float* t_out = C->t_out;
+                    unsigned long long* idx_out = C->idx_out;
+                    uint8_t* shadowed_out = C->shadowed_out;
+                    if (t_out) t_out[r] = best_t;
+                    if (idx_out) idx_out[r] = R.best_idx;
+                    if (shadowed_out) shadowed_out[r] = R.best_idx != ~0ull ? 1 : 0;
+                }
+                busy = false;
+                r = ~0ull;
             }
-            busy = false;
-            r = ~0ull;
         }
+        VX_UTIL_T(4)
     }
+#ifdef VX_TRACE_DEBUG_UTIL
+    if (lane == 0)
+        for (int i = 0; i < 11; ++i) atomicAdd(&g_trace_util[i], dbg_c[i]);
+#endif
 }
+
+#ifdef VX_TRACE_DEBUG_UTIL
+}  // namespace vx
+extern "C" int vx_debug_trace_util(unsigned long long* out16, int reset)
+{
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(vx::g_trace_util), 16 * 8) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(vx::g_trace_util), z, 16 * 8) != hipSuccess) return 1; }
+    return 0;
+}
+namespace vx {
+#endif
 
 // outputs of the rays that were split by work donation, from their merged keys
 __global__ __launch_bounds__(256) void k_merge_list(const uint32_t* __restrict__ list, const unsigned long long* __restrict__ nlist,
@@ -795,21 +832,6 @@ __global__ __launch_bounds__(256) void k_merge_list(const uint32_t* __restrict__
     const unsigned long long n = *nlist;
     for (unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256u) {
         const uint32_t r = list[i];
-        const unsigned long long k = keys[r];
-        if (t_out) t_out[r] = k == ~0ull ? -1.0f : __uint_as_float((uint32_t)(k >> 32));
-        if (idx_out) idx_out[r] = k == ~0ull ? ~0ull : (k & 0xFFFFFFFFull);
-        if (shadowed_out) shadowed_out[r] = k == ~0ull ? 0 : 1;
-    }
-}
-
-// outputs of the spilled rays from their merged keys
-__global__ __launch_bounds__(256) void k_merge(const Spill* __restrict__ spill, const unsigned long long* __restrict__ nspill,
-                                               const unsigned long long* __restrict__ keys, float* __restrict__ t_out,
-                                               unsigned long long* __restrict__ idx_out, uint8_t* __restrict__ shadowed_out)
-{
-    const unsigned long long n = *nspill;
-    for (unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256u) {
-        const uint32_t r = spill[i].ray;
         const unsigned long long k = keys[r];
         if (t_out) t_out[r] = k == ~0ull ? -1.0f : __uint_as_float((uint32_t)(k >> 32));
         if (idx_out) idx_out[r] = k == ~0ull ? ~0ull : (k & 0xFFFFFFFFull);
@@ -877,57 +899,57 @@ __global__ __launch_bounds__(256) void k_rank(const float* __restrict__ t, const
     }
 }
 
-size_t trace_spill_bytes(uint64_t nrays) { return (size_t)nrays * sizeof(Spill) + 64; }
+size_t trace_spill_bytes(uint64_t nrays) { return (size_t)nrays * sizeof(uint32_t) + 64; }  // list of split rays
 
 void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* word_prefix, const TraceIO& io, unsigned long long* counters /*>= 4*/,
                   unsigned long long* idx_tmp, void* spill_buf, unsigned long long* keys, hipStream_t s)
 {
     const uint64_t nrays = io.nrays;
     if (!nrays) return;
-    // counters[0]: work counter of the main pass, [1]: number of spilled rays, [2]: work counter of the segment pass
-    (void)hipMemsetAsync(counters, 0, 3 * sizeof(unsigned long long), s);
-    const Camera* c = io.cam_dev;  // device copy of the camera (null for explicit rays)
+    // counters[0]: work counter, [1]: number of rays split by work donation
+    (void)hipMemsetAsync(counters, 0, 2 * sizeof(unsigned long long), s);
     const uint64_t n1 = (uint64_t)mips.d1[0] * mips.d1[1] * mips.d1[2];
     const uint32_t m1_words = (uint32_t)((n1 + 31) / 32);
     const bool lds_m1 = (size_t)m1_words * 4 <= 40960;  // 4 workgroups x 40 KiB fit the CU's 160 KiB
     // persistent grid: 256 CUs x 4 resident 256-thread workgroups, fewer when there are not that many rays
     static const int env_blocks = getenv("VOXHIP_TRACE_BLOCKS") ? atoi(getenv("VOXHIP_TRACE_BLOCKS")) : 1024;
-    // ray splitting is OFF by default: measured on 1M incoherent rays it costs more than it saves (0.82 ms single pass vs
-    // 0.86-0.97 ms split) -- the kernel is bound by instruction issue at low lane utilisation, not by its longest ray
-    static const int env_budget = getenv("VOXHIP_TRACE_BUDGET") ? atoi(getenv("VOXHIP_TRACE_BUDGET")) : 0;
-    static const int env_nseg = getenv("VOXHIP_TRACE_NSEG") ? atoi(getenv("VOXHIP_TRACE_NSEG")) : 8;
     uint64_t nblk = (nrays + 255) / 256;
     if (nblk > (uint64_t)env_blocks) nblk = (uint64_t)env_blocks;
     const dim3 grid((unsigned)nblk), block(256);
     const bool want_rank = (io.prim_out || io.hits || io.normal_out) && word_prefix && idx_tmp && io.t_out;
     unsigned long long* idx_out = want_rank ? idx_tmp : nullptr;
     const size_t shmem = lds_m1 ? (size_t)m1_words * 4 : 0;
-    // ray splitting needs the voxel index in 32 bits of the merge key and rays numbered in 32 bits
-    const bool mergeable = spill_buf && keys && g.nvox <= 0x100000000ull && nrays < 0xFFFFFFFFull;
-    const bool split = env_budget > 0 && env_nseg > 1 && mergeable;
-    Spill* sp = split ? (Spill*)spill_buf : nullptr;
-    const int budget = split ? env_budget : 0;
-    // intra-wave work donation in the drain phase (default on; VOXHIP_TRACE_DONATE=0 disables); it shares the ray list /
-    // key machinery with the budget split, so the two are not combined
+    // intra-wave work donation in the drain phase (default on; VOXHIP_TRACE_DONATE=0 disables).  The merge key holds the
+    // voxel index in 32 bits and the list holds ray numbers in 32 bits.
     static const int env_donate = getenv("VOXHIP_TRACE_DONATE") ? atoi(getenv("VOXHIP_TRACE_DONATE")) : 1;
-    const bool donate = env_donate && mergeable && !split;
+    const bool donate = env_donate && spill_buf && keys && g.nvox <= 0x100000000ull && nrays < 0xFFFFFFFFull;
     uint32_t* dlist = donate ? (uint32_t*)spill_buf : nullptr;
     if (donate) (void)hipMemsetAsync(keys, 0xFF, (size_t)nrays * 8, s);  // "no hit" in every ray's merge key
-#define VX_LAUNCH(L, SEG, GRID, CNT)                                                                                                             \
-    VX_KL((k_trace<L, SEG>), GRID, block, shmem, s, g, mips, io.rays, c, nrays, io.tmin, io.tmax, io.tmax_per_ray, io.any_hit ? 1 : 0, io.t_out, idx_out, \
-          io.shadowed_out, CNT, sp, counters + 1, keys, budget, env_nseg, m1_words, dlist)
-    if (lds_m1) VX_LAUNCH(true, false, grid, counters); else VX_LAUNCH(false, false, grid, counters);
-    if (split) {
-        const dim3 sgrid((unsigned)env_blocks);
-        if (lds_m1) VX_LAUNCH(true, true, sgrid, counters + 2); else VX_LAUNCH(false, true, sgrid, counters + 2);
-        VX_KL(k_merge, dim3(256), block, 0, s, sp, counters + 1, keys, io.t_out, idx_out, io.shadowed_out);
-    }
+    TraceParams P;
+    std::memset(&P, 0, sizeof(P));
+    P.hot.g = g;
+    P.hot.M = mips;
+    P.hot.tmin = io.tmin;
+    P.hot.any_hit = io.any_hit ? 1 : 0;
+    P.hot.m1_words = m1_words;
+    P.cold.rays = io.rays;
+    P.cold.cam = io.cam_dev;  // device copy of the camera (null for explicit rays)
+    P.cold.tmax_per_ray = io.tmax_per_ray;
+    P.cold.tmax = io.tmax;
+    P.cold.nrays = nrays;
+    P.cold.t_out = io.t_out;
+    P.cold.idx_out = idx_out;
+    P.cold.shadowed_out = io.shadowed_out;
+    P.cold.next_item = counters;
+    P.cold.nsplit = counters + 1;
+    P.cold.keys = keys;
+    P.cold.split_list = dlist;
+    if (lds_m1) { VX_KL(k_trace<true>, grid, block, shmem, s, P); } else { VX_KL(k_trace<false>, grid, block, shmem, s, P); }
     if (donate) VX_KL(k_merge_list, dim3(256), block, 0, s, dlist, counters + 1, keys, io.t_out, idx_out, io.shadowed_out);
-#undef VX_LAUNCH
     if (want_rank) {
         if (io.hits && io.nhits) (void)hipMemsetAsync(io.nhits, 0, sizeof(unsigned long long), s);
         const dim3 rgrid((unsigned)((nrays + 255) / 256));
-        VX_KL(k_rank, rgrid, block, 0, s, io.t_out, idx_tmp, nrays, g, mips.w0, word_prefix, io.rays, c, io.prim_out, io.normal_out, io.hits, io.nhits);
+        VX_KL(k_rank, rgrid, block, 0, s, io.t_out, idx_tmp, nrays, g, mips.w0, word_prefix, io.rays, io.cam_dev, io.prim_out, io.normal_out, io.hits, io.nhits);
     }
 }
 

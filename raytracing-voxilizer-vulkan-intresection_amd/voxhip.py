@@ -58,7 +58,7 @@ SYMBOLS = [
     "vx_octree_build", "vx_octree_num_items", "vx_octree_num_nodes", "vx_octree_bytes", "vx_octree_items", "vx_octree_nodes",
     "vx_octree_root_bounds", "vx_octree_aabbs", "vx_octree_aabbs_device", "vx_octree_free",
     "vx_trace", "vx_trace_device", "vx_trace_primary_device", "vx_trace_ex", "vx_trace_ex_device",
-    "vx_profile_enable", "vx_profile_reset", "vx_profile_read",
+    "vx_profile_enable", "vx_profile_select", "vx_profile_reset", "vx_profile_read",
     "vx_shard_words", "vx_shard_range",
 ]
 
@@ -151,6 +151,7 @@ def lib():
     L.vx_trace_device.argtypes = [vp, vp, C.c_uint64, C.c_float, C.c_float, vp, vp, vp, vp]
     L.vx_trace_primary_device.argtypes = [vp, fp, fp, C.c_uint32, C.c_uint32, C.c_float, C.c_float, vp, vp]
     L.vx_profile_enable.argtypes = [C.c_int]
+    L.vx_profile_select.argtypes = [C.c_char_p]
     L.vx_profile_read.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), u64p]
     L.vx_trace_ex.argtypes = [vp, C.POINTER(TraceArgs)]
     L.vx_trace_ex_device.argtypes = [vp, C.POINTER(TraceArgs)]
@@ -177,6 +178,11 @@ def set_device(d):
 
 def profile_enable(on=True):
     lib().vx_profile_enable(1 if on else 0)
+
+
+def profile_select(kernel=None):
+    """Time only this kernel (bare name); None = all kernels."""
+    lib().vx_profile_select(kernel.encode() if kernel else None)
 
 
 def profile_reset():
