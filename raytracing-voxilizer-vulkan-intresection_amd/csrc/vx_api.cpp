@@ -99,12 +99,13 @@ struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
     int dev = 0;
+    bool fresh = false;  // set when ensure() handed out a new block (contents undefined); the owner clears it
     hipError_t ensure(size_t bytes)
     {
         if (bytes <= cap && p) return hipSuccess;
         release();
         hipError_t e = pool_alloc(dev, bytes, &p);
-        if (e == hipSuccess) cap = round_size(bytes);
+        if (e == hipSuccess) { cap = round_size(bytes); fresh = true; }
         return e;
     }
     void release()
@@ -137,15 +138,52 @@ vx_status need_device(int dev)
 
 // small per-handle scratch in device memory
 struct Small {
-    unsigned long long keys[6];
-    float bbox[6];
-    float pad0[2];
+    unsigned long long bbox_state[8];  // K1's self-cleaning reduction state (initialised once, see ensure_small)
     unsigned long long set_calls;
-    unsigned long long total_a;
-    unsigned long long total_b;
     unsigned long long nhits;
     unsigned long long trace_counters[4];
 };
+
+// The few values the HOST waits for (bbox -> grid dims, unit / hit / occupied counts -> buffer sizes).  Kernels write them
+// straight into pinned host memory; the host reads them after a stream synchronize.  No device-to-host copy kernel, no
+// staging through pageable memory.
+struct Mail {
+    float bbox[8];
+    unsigned long long units, hits, occupied, pad;
+};
+
+hipError_t mail_alloc(Mail** out)
+{
+    void* p = nullptr;
+    const hipError_t e = hipHostMalloc(&p, sizeof(Mail), hipHostMallocCoherent);
+    if (e != hipSuccess) return e;
+    std::memset(p, 0, sizeof(Mail));
+    *out = reinterpret_cast<Mail*>(p);
+    return hipSuccess;
+}
+
+// (re)allocated Small: the bbox reduction state needs its initial values once; everything else starts at zero
+hipError_t ensure_small(DevBuf& small)
+{
+    hipError_t e = small.ensure(sizeof(Small));
+    if (e != hipSuccess || !small.fresh) return e;
+    Small h;
+    std::memset(&h, 0, sizeof(h));
+    vx::bbox_state_init(h.bbox_state);
+    e = hipMemcpy(small.p, &h, sizeof(h), hipMemcpyHostToDevice);
+    if (e == hipSuccess) small.fresh = false;
+    return e;
+}
+
+// scan scratch with the "all zero between scans" contract of launch_scan_u32(..., tmp_is_zero = true)
+hipError_t ensure_scan_tmp(DevBuf& tmp, size_t bytes, hipStream_t s)
+{
+    hipError_t e = tmp.ensure(bytes);
+    if (e != hipSuccess || !tmp.fresh) return e;
+    e = hipMemsetAsync(tmp.p, 0, tmp.cap, s);
+    if (e == hipSuccess) tmp.fresh = false;
+    return e;
+}
 
 }  // namespace
 
@@ -171,9 +209,10 @@ struct vx_grid {
     uint64_t triangles = 0;
     uint32_t cdim[3] = {0, 0, 0}, c2dim[3] = {0, 0, 0};
     DevBuf words, cwords, c2words, bricks, bbounds, idxtmp, ttmp, spill, keys, camera, wprefix, recs, units, ubase, btri, umask, hbase, scantmp, small, vec;
-    bool coarse_valid = false, prefix_valid = false, counts_valid = true;
+    bool coarse_valid = false, prefix_valid = false /*word_prefix queued or done*/, occupied_known = false, counts_valid = true;
     uint64_t occupied = 0, set_calls = 0, host_set_calls = 0;
     uint64_t vec_count = 0;
+    Mail* mail = nullptr;
     void set_dev(int d)
     {
         device = d;
@@ -182,6 +221,8 @@ struct vx_grid {
     void release_all()
     {
         for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &bbounds, &idxtmp, &ttmp, &spill, &keys, &camera, &wprefix, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec}) b->release();
+        if (mail) (void)hipHostFree(mail);
+        mail = nullptr;
     }
 };
 
@@ -222,12 +263,12 @@ struct Extent {
     uint64_t dim[3];
 };
 
-vx_status compute_extent(const vx_mesh* m, float vs, Small* dsmall, hipStream_t s, Extent* e)
+vx_status compute_extent(const vx_mesh* m, float vs, Small* dsmall, Mail* mail, hipStream_t s, Extent* e)
 {
-    vx::launch_bbox(m->dv, m->nv, dsmall->keys, dsmall->bbox, s);
-    float bb[6];
-    VX_HIP(hipMemcpyAsync(bb, dsmall->bbox, sizeof(bb), hipMemcpyDeviceToHost, s));
+    // one kernel: reduction, result into the host mailbox, state restored, per-build setVoxel counter cleared
+    vx::launch_bbox(m->dv, m->nv, dsmall->bbox_state, mail->bbox, &dsmall->set_calls, s);
     VX_HIP(hipStreamSynchronize(s));
+    const float* bb = mail->bbox;
     for (int a = 0; a < 3; ++a) {
         e->mn[a] = bb[a];
         e->mx[a] = bb[3 + a];
@@ -257,19 +298,24 @@ void fill_params(vx::GridParams& g, const float org[3], float vs, const uint64_t
 
 constexpr uint64_t kMaxVoxels = 1ull << 37;  // 16 GiB of bitmask
 
-// The shared front half of buildVoxelGrid for grids and the octree: records, unit counts, unit bases.
-vx_status run_setup(const vx_mesh* m, const vx::GridParams& g, int sat, uint64_t tb, uint32_t ntri, uint32_t zlo, uint32_t zhi, DevBuf& recs,
-                    DevBuf& units, DevBuf& ubase, DevBuf& btri, DevBuf& scantmp, Small* ds, hipStream_t s, uint64_t* total_units)
+// The shared front half of buildVoxelGrid for grids and the octree: records, unit counts, unit bases.  In two parts so that
+// the caller can queue work that does not depend on the unit count (clearing the bitmask) before the host waits for it.
+vx_status setup_launch(const vx_mesh* m, const vx::GridParams& g, int sat, uint64_t tb, uint32_t ntri, uint32_t zlo, uint32_t zhi, DevBuf& recs,
+                       DevBuf& units, DevBuf& ubase, DevBuf& scantmp, Mail* mail, hipStream_t s)
 {
     VX_HIP(recs.ensure((size_t)ntri * sizeof(vx::TriRec) + 64));
     VX_HIP(units.ensure(((size_t)ntri + 1) * 4));
     VX_HIP(ubase.ensure(((size_t)ntri + 2) * 4));
-    VX_HIP(scantmp.ensure(vx::scan_tmp_bytes(ntri)));
+    VX_HIP(ensure_scan_tmp(scantmp, vx::scan_tmp_bytes(ntri), s));
     vx::launch_tri_setup(m->dv, m->di, tb, ntri, g, sat, zlo, zhi, recs.as<vx::TriRec>(), units.as<uint32_t>(), s);
-    vx::launch_scan_u32(units.as<uint32_t>(), ubase.as<uint32_t>(), ntri, false, scantmp.p, &ds->total_a, s);
-    unsigned long long tot = 0;
-    VX_HIP(hipMemcpyAsync(&tot, &ds->total_a, 8, hipMemcpyDeviceToHost, s));
+    vx::launch_scan_u32(units.as<uint32_t>(), ubase.as<uint32_t>(), ntri, false, scantmp.p, &mail->units, s, true);
+    return VX_OK;
+}
+
+vx_status setup_finish(uint32_t ntri, DevBuf& ubase, DevBuf& btri, Mail* mail, hipStream_t s, uint64_t* total_units)
+{
     VX_HIP(hipStreamSynchronize(s));
+    const unsigned long long tot = mail->units;
     if (tot >= 0xFFFFFFFFull) return fail(VX_ERR_CAPACITY, "more than 2^32 candidate row segments: shard the mesh or the grid");
     *total_units = tot;
     if (tot) {
@@ -283,31 +329,30 @@ vx_status run_setup(const vx_mesh* m, const vx::GridParams& g, int sat, uint64_t
 // count (a host sync in front of a kernel leaves the GPU idle and the clocks down for its start).
 vx_status prefix_launch(vx_grid* g, bool* pending)
 {
-    *pending = false;
+    *pending = !g->occupied_known;
     if (g->prefix_valid) return VX_OK;
     VX_HIP(g->wprefix.ensure((size_t)(g->g.nwords + 2) * 4));
-    VX_HIP(g->scantmp.ensure(vx::scan_tmp_bytes(g->g.nwords)));
-    Small* ds = g->small.as<Small>();
-    vx::launch_scan_u32(g->words.as<uint32_t>(), g->wprefix.as<uint32_t>(), g->g.nwords, true, g->scantmp.p, &ds->total_b, g->stream);
+    VX_HIP(ensure_scan_tmp(g->scantmp, vx::scan_tmp_bytes(g->g.nwords), g->stream));
+    vx::launch_scan_u32(g->words.as<uint32_t>(), g->wprefix.as<uint32_t>(), g->g.nwords, true, g->scantmp.p, &g->mail->occupied, g->stream, true);
+    g->prefix_valid = true;
+    g->occupied_known = false;
     *pending = true;
     return VX_OK;
 }
 
 vx_status prefix_finish(vx_grid* g, bool pending)
 {
-    if (!pending) return VX_OK;
-    unsigned long long tot = 0;
-    VX_HIP(hipMemcpyAsync(&tot, &g->small.as<Small>()->total_b, 8, hipMemcpyDeviceToHost, g->stream));
+    if (!pending || g->occupied_known) return VX_OK;
     VX_HIP(hipStreamSynchronize(g->stream));
+    const unsigned long long tot = g->mail->occupied;
     if (tot >= 0xFFFFFFFFull) return fail(VX_ERR_CAPACITY, "more than 2^32 occupied voxels");
     g->occupied = tot;
-    g->prefix_valid = true;
+    g->occupied_known = true;
     return VX_OK;
 }
 
 vx_status ensure_prefix(vx_grid* g)
 {
-    if (g->prefix_valid) return VX_OK;
     DeviceGuard dg(g->device);
     bool pending = false;
     VX_TRY(prefix_launch(g, &pending));
@@ -331,7 +376,7 @@ vx_status ensure_coarse(vx_grid* g)
     // bitmask -> brick-major slices -> per-brick bounds + level-1 mip -> level-2 mip
     vx::launch_build_bricks(g->words.as<uint32_t>(), g->g.dim, g->cdim, g->bricks.as<unsigned long long>(), g->stream);
     vx::launch_brick_bounds(g->bricks.as<unsigned long long>(), nc, g->bbounds.as<uint32_t>(), g->cwords.as<uint32_t>(), g->stream);
-    vx::launch_build_coarse(g->cwords.as<uint32_t>(), g->cdim, g->c2dim, g->c2words.as<uint32_t>(), g->stream);
+    vx::launch_build_mip2(g->cwords.as<uint32_t>(), g->cdim, g->c2dim, g->c2words.as<uint32_t>(), g->stream);
     g->coarse_valid = true;
     return VX_OK;
 }
@@ -348,13 +393,17 @@ vx_status sync_counts(vx_grid* g)
     return VX_OK;
 }
 
-vx_status init_grid_storage(vx_grid* g)
+// `clear`: zero the bitmask and the call counter now (false: the caller queues that itself)
+vx_status init_grid_storage(vx_grid* g, bool clear = true)
 {
-    VX_HIP(g->small.ensure(sizeof(Small)));
+    VX_HIP(ensure_small(g->small));
+    if (!g->mail) VX_HIP(mail_alloc(&g->mail));
     VX_HIP(g->words.ensure((size_t)(g->g.nwords + 2) * 4));
-    VX_HIP(hipMemsetAsync(g->words.p, 0, (size_t)(g->g.nwords + 2) * 4, g->stream));
-    VX_HIP(hipMemsetAsync(&g->small.as<Small>()->set_calls, 0, 8, g->stream));
-    g->coarse_valid = g->prefix_valid = false;
+    if (clear) {
+        VX_HIP(hipMemsetAsync(g->words.p, 0, (size_t)(g->g.nwords + 2) * 4, g->stream));
+        VX_HIP(hipMemsetAsync(&g->small.as<Small>()->set_calls, 0, 8, g->stream));
+    }
+    g->coarse_valid = g->prefix_valid = g->occupied_known = false;
     g->counts_valid = true;
     g->occupied = g->set_calls = g->host_set_calls = g->vec_count = 0;
     return VX_OK;
@@ -491,15 +540,17 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
     hipStream_t s = g->stream;
     if (o.sat_variant != 0 && o.sat_variant != 1) return fail(VX_ERR_INVALID_ARG, "sat_variant must be 0 or 1");
 
-    VX_HIP(g->small.ensure(sizeof(Small)));
+    VX_HIP(ensure_small(g->small));
+    if (!g->mail) VX_HIP(mail_alloc(&g->mail));
     Small* ds = g->small.as<Small>();
     Extent ex;
-    VX_TRY(compute_extent(mesh, vs, ds, s, &ex));
+    VX_TRY(compute_extent(mesh, vs, ds, g->mail, s, &ex));  // also clears the per-build call counter
     const uint64_t nvox = ex.dim[0] * ex.dim[1] * ex.dim[2];
     if (nvox > kMaxVoxels) return fail(VX_ERR_CAPACITY, "grid exceeds 2^37 voxels");
     fill_params(g->g, ex.mn, vs, ex.dim);
     for (int a = 0; a < 3; ++a) { g->bbmin[a] = ex.mn[a]; g->bbmax[a] = ex.mx[a]; g->bbc[a] = ex.ctr[a]; }
-    VX_TRY(init_grid_storage(g));
+    VX_TRY(init_grid_storage(g, /*clear=*/false));
+    const size_t mask_bytes = (size_t)(g->g.nwords + 2) * 4;
 
     uint64_t tb = 0, te = mesh->nt;
     if (o.tri_begin || o.tri_end) {
@@ -515,7 +566,10 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
     }
     g->triangles = te - tb;
     const uint32_t ntri = (uint32_t)(te - tb);
-    if (ntri == 0 || nvox == 0 || wb == we) return VX_OK;
+    if (ntri == 0 || nvox == 0 || wb == we) {
+        VX_HIP(hipMemsetAsync(g->words.p, 0, mask_bytes, s));
+        return VX_OK;
+    }
 
     // z slab that contains the voxels of words [wb, we)
     const uint64_t XY = ex.dim[0] * ex.dim[1];
@@ -524,8 +578,11 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
     if (zh > ex.dim[2]) zh = ex.dim[2];
     const uint32_t zhi = (uint32_t)zh;
 
+    // records + unit scan are queued, THEN the bitmask is cleared (it does not depend on the unit count), then the host waits
+    VX_TRY(setup_launch(mesh, g->g, o.sat_variant, tb, ntri, zlo, zhi, g->recs, g->units, g->ubase, g->scantmp, g->mail, s));
+    VX_HIP(hipMemsetAsync(g->words.p, 0, mask_bytes, s));
     uint64_t U = 0;
-    VX_TRY(run_setup(mesh, g->g, o.sat_variant, tb, ntri, zlo, zhi, g->recs, g->units, g->ubase, g->btri, g->scantmp, ds, s, &U));
+    VX_TRY(setup_finish(ntri, g->ubase, g->btri, g->mail, s, &U));
     if (U == 0) return VX_OK;
     uint32_t* umask = nullptr;
     if (g->kind == VX_GRID_VEC) {
@@ -538,12 +595,28 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
     if (g->kind == VX_GRID_VEC) {
         // VoxelGridVec::setVoxel appends one Aabb per call (voxelgridVecEncoding.cpp:19-39): ordered emission
         VX_HIP(g->hbase.ensure((size_t)(U + 2) * 4));
-        VX_HIP(g->scantmp.ensure(vx::scan_tmp_bytes(U)));
-        vx::launch_scan_u32(umask, g->hbase.as<uint32_t>(), U, true, g->scantmp.p, &ds->total_b, s);
-        unsigned long long hits = 0;
-        VX_HIP(hipMemcpyAsync(&hits, &ds->total_b, 8, hipMemcpyDeviceToHost, s));
+        VX_HIP(ensure_scan_tmp(g->scantmp, vx::scan_tmp_bytes(U), s));
+        vx::launch_scan_u32(umask, g->hbase.as<uint32_t>(), U, true, g->scantmp.p, &g->mail->hits, s, true);
+    }
+    // A complete (unsharded) bitmask: queue what every consumer of the grid needs next -- the traversal structure (bricks,
+    // bounds, mips = the reference's acceleration-structure build, hello_vulkan.cpp:700-703) and the word prefix (getAabbs /
+    // primitive ids) -- behind the voxelizer instead of lazily in front of the first query.  For the Vec flavour this work
+    // runs while the host waits for the hit count.  VOXHIP_EAGER=0 keeps it lazy.
+    static const bool eager = !(getenv("VOXHIP_EAGER") && atoi(getenv("VOXHIP_EAGER")) == 0);
+    if (eager && wb == 0 && we == g->g.nwords) {
+        VX_TRY(ensure_coarse(g));
+        bool pending = false;
+        VX_TRY(prefix_launch(g, &pending));
+    }
+    if (g->kind == VX_GRID_VEC) {
         VX_HIP(hipStreamSynchronize(s));
+        const unsigned long long hits = g->mail->hits;
         if (hits >= 0xFFFFFFFFull) return fail(VX_ERR_CAPACITY, "more than 2^32 voxel hits");
+        if (g->prefix_valid) {  // the same wait covered the occupied count
+            if (g->mail->occupied >= 0xFFFFFFFFull) return fail(VX_ERR_CAPACITY, "more than 2^32 occupied voxels");
+            g->occupied = g->mail->occupied;
+            g->occupied_known = true;
+        }
         VX_HIP(g->vec.ensure((size_t)(hits + 1) * sizeof(vx_aabb)));
         vx::launch_emit_units(g->recs.as<vx::TriRec>(), g->ubase.as<uint32_t>(), g->btri.as<uint32_t>(), ntri, g->g, umask,
                               g->hbase.as<uint32_t>(), g->vec.as<vx_aabb>(), nullptr, s);
@@ -642,7 +715,7 @@ vx_status vx_grid_set_voxel(vx_grid* g, uint64_t x, uint64_t y, uint64_t z)
     }
     g->host_set_calls++;
     g->set_calls++;
-    g->coarse_valid = g->prefix_valid = false;
+    g->coarse_valid = g->prefix_valid = g->occupied_known = false;
     return VX_OK;
 }
 
@@ -695,13 +768,13 @@ const uint32_t* vx_grid_bitmask_device(const vx_grid* g) { return g ? g->words.a
 uint32_t* vx_grid_bitmask_device_mut(vx_grid* g)
 {
     if (!g) return nullptr;
-    g->coarse_valid = g->prefix_valid = false;
+    g->coarse_valid = g->prefix_valid = g->occupied_known = false;
     return g->words.as<uint32_t>();
 }
 vx_status vx_grid_refresh(vx_grid* g)
 {
     if (!g) return fail(VX_ERR_INVALID_ARG, "null argument");
-    g->coarse_valid = g->prefix_valid = false;
+    g->coarse_valid = g->prefix_valid = g->occupied_known = false;
     VX_TRY(ensure_prefix(g));
     return ensure_coarse(g);
 }
@@ -770,7 +843,8 @@ static vx_status trace_common(vx_grid* g, vx::TraceIO io)
     const uint32_t* prefix = nullptr;
     unsigned long long* idx_tmp = nullptr;
     if (io.prim_out || io.hits || io.normal_out) {
-        VX_TRY(ensure_prefix(g));
+        bool pending = false;
+        VX_TRY(prefix_launch(g, &pending));  // the ranks need the prefix array on the stream, not the count on the host
         prefix = g->wprefix.as<uint32_t>();
         VX_HIP(g->idxtmp.ensure((size_t)io.nrays * 8 + 8));
         idx_tmp = g->idxtmp.as<unsigned long long>();
@@ -936,14 +1010,20 @@ vx_status vx_octree_build(const vx_mesh* mesh_c, float vs, uint64_t max_items, v
     o->items.dev = o->device;
     DevBuf small, recs, units, ubase, btri, scantmp, umask, hbase, unsorted, sorttmp;
     for (DevBuf* b : {&small, &recs, &units, &ubase, &btri, &scantmp, &umask, &hbase, &unsorted, &sorttmp}) b->dev = o->device;
-    auto cleanup = [&]() { for (DevBuf* b : {&small, &recs, &units, &ubase, &btri, &scantmp, &umask, &hbase, &unsorted, &sorttmp}) b->release(); };
+    Mail* mail = nullptr;
+    auto cleanup = [&]() {
+        for (DevBuf* b : {&small, &recs, &units, &ubase, &btri, &scantmp, &umask, &hbase, &unsorted, &sorttmp}) b->release();
+        if (mail) (void)hipHostFree(mail);
+        mail = nullptr;
+    };
     auto bail = [&](vx_status st) { cleanup(); o->items.release(); if (o->dnodes) (void)hipFree(o->dnodes); delete o; return st; };
 #define OCT_HIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return bail(fail(VX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__))); } while (0)
 #define OCT_TRY(expr) do { vx_status s__ = (expr); if (s__ != VX_OK) return bail(s__); } while (0)
-    OCT_HIP(small.ensure(sizeof(Small)));
+    OCT_HIP(ensure_small(small));
     Small* ds = small.as<Small>();
+    OCT_HIP(mail_alloc(&mail));
     Extent ex;
-    OCT_TRY(compute_extent(mesh, vs, ds, s, &ex));
+    OCT_TRY(compute_extent(mesh, vs, ds, mail, s, &ex));
     for (int a = 0; a < 3; ++a) { o->root_min[a] = ex.mn[a]; o->root_max[a] = ex.mx[a]; o->dim[a] = ex.dim[a]; }
     uint64_t maxDim = ex.dim[0] > ex.dim[1] ? ex.dim[0] : ex.dim[1];
     if (ex.dim[2] > maxDim) maxDim = ex.dim[2];
@@ -957,17 +1037,17 @@ vx_status vx_octree_build(const vx_mesh* mesh_c, float vs, uint64_t max_items, v
     vx::GridParams g;
     fill_params(g, ex.mn, vs, ex.dim);
     uint64_t U = 0;
-    OCT_TRY(run_setup(mesh, g, /*sat a7: octTree.hpp:762*/ 0, 0, ntri, 0, (uint32_t)ex.dim[2], recs, units, ubase, btri, scantmp, ds, s, &U));
+    OCT_TRY(setup_launch(mesh, g, /*sat a7: octTree.hpp:762*/ 0, 0, ntri, 0, (uint32_t)ex.dim[2], recs, units, ubase, scantmp, mail, s));
+    OCT_TRY(setup_finish(ntri, ubase, btri, mail, s, &U));
     unsigned long long hits = 0;
     if (U) {
         OCT_HIP(umask.ensure((size_t)(U + 1) * 4));
         OCT_HIP(hbase.ensure((size_t)(U + 2) * 4));
-        OCT_HIP(scantmp.ensure(vx::scan_tmp_bytes(U)));
-        OCT_HIP(hipMemsetAsync(&ds->set_calls, 0, 8, s));
+        OCT_HIP(ensure_scan_tmp(scantmp, vx::scan_tmp_bytes(U), s));
         vx::launch_voxelize(recs.as<vx::TriRec>(), ubase.as<uint32_t>(), btri.as<uint32_t>(), ntri, g, 0, nullptr, 0, 0, umask.as<uint32_t>(), &ds->set_calls, s);
-        vx::launch_scan_u32(umask.as<uint32_t>(), hbase.as<uint32_t>(), U, true, scantmp.p, &ds->total_b, s);
-        OCT_HIP(hipMemcpyAsync(&hits, &ds->total_b, 8, hipMemcpyDeviceToHost, s));
+        vx::launch_scan_u32(umask.as<uint32_t>(), hbase.as<uint32_t>(), U, true, scantmp.p, &mail->hits, s, true);
         OCT_HIP(hipStreamSynchronize(s));
+        hits = mail->hits;
         if (hits >= 0xFFFFFFFFull) return bail(fail(VX_ERR_CAPACITY, "more than 2^32 octree items"));
     }
     o->nitems = hits;

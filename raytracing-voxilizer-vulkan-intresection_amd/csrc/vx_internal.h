@@ -41,7 +41,10 @@ struct ProfScope {
 
 // ---- launchers (all asynchronous on `s`) ------------------------------------------------------------------
 // K1: bbox of all vertices with the reference's first-occurrence tie rule; out6 = min xyz, max xyz (device).
-void launch_bbox(const float* verts, uint64_t nverts, unsigned long long* keys6, float* out6, hipStream_t s);
+// state7: self-cleaning reduction state (initialise ONCE with bbox_state_init); out6 may point to pinned host memory;
+// zero64 (optional) is cleared by the kernel.
+void bbox_state_init(unsigned long long state7[7]);
+void launch_bbox(const float* verts, uint64_t nverts, unsigned long long* state7, float* out6, unsigned long long* zero64, hipStream_t s);
 
 // K2a: per-triangle record + number of row-segment work units; zlo/zhi clamp the candidate box to a z slab.
 void launch_tri_setup(const float* verts, const int32_t* idx, uint64_t tri_begin, uint32_t ntri, const GridParams& g,
@@ -49,8 +52,9 @@ void launch_tri_setup(const float* verts, const int32_t* idx, uint64_t tri_begin
 
 // exclusive scan of n uint32 (or of their popcounts) into out[0..n] (out[n] = total, saturating check via *total64)
 size_t scan_tmp_bytes(uint64_t n);
+// tmp_is_zero: the caller guarantees tmp (scan_tmp_bytes(n)) is all zero; the scan leaves it all zero again.
 void launch_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, bool popcount_input, void* tmp,
-                     unsigned long long* total64, hipStream_t s);
+                     unsigned long long* total64, hipStream_t s, bool tmp_is_zero = false);
 
 // K2: triangle/voxel overlap over all work units; ORs hits into `words` (only words in [wb,we)), optionally
 // stores each unit's 32-bit hit mask (unit_mask) for the ordered emitters; adds the hit count to *set_calls.
@@ -71,7 +75,7 @@ void launch_emit_bool_aabbs(const uint32_t* words, const uint32_t* word_prefix, 
 void launch_emit_morton_aabbs(const uint64_t* items, uint64_t n, const float root_min[3], float vs, vx_aabb* out, hipStream_t s);
 
 // occupancy mip for the ray kernel: one bit per 8^3 cells of the level below (fdim = dims of that level)
-void launch_build_coarse(const uint32_t* words, const uint32_t fdim[3], const uint32_t cdim[3], uint32_t* cwords, hipStream_t s);
+void launch_build_mip2(const uint32_t* m1, const uint32_t d1[3], const uint32_t d2[3], uint32_t* m2, hipStream_t s);
 
 // K6: first hit per ray.  Three-level occupancy hierarchy: cells (bricks; w0 = the reference-layout bitmask, used for the
 // primitive rank only), 8^3 bricks (w1, dims d1), 64^3 blocks (w2, dims d2).

@@ -13,6 +13,8 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (bit-exact float semantics, see vx_math.h).
 #include "vx_internal.h"
 
+#include <cstdlib>
+
 #pragma clang fp contract(off)
 
 namespace vx {
@@ -43,6 +45,10 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
     hi = __shfl_xor(hi, m, 64);
     return ((unsigned long long)hi << 32) | lo;
 }
+__device__ __forceinline__ unsigned long long shfl_u64_k(unsigned long long v, int src)
+{
+    return ((unsigned long long)__shfl((unsigned)(v >> 32), src, 64) << 32) | __shfl((unsigned)v, src, 64);
+}
 __device__ __forceinline__ unsigned wave_sum_u32(unsigned v)
 {
 #pragma unroll
@@ -69,7 +75,12 @@ __device__ __forceinline__ unsigned ord_bits(float f)
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-__global__ __launch_bounds__(256) void k_bbox(const float* __restrict__ verts, uint64_t nverts, unsigned long long* keys)
+// state[0..5]: keys (min x,y,z / max x,y,z), state[6]: number of finished workgroups.  The state is self-cleaning: the last
+// workgroup to finish reads the result, writes the six floats and restores the initial values, so a rebuild needs neither a
+// host-to-device initialisation nor a second kernel.  `zero64` (optional) is cleared by the same workgroup: the per-build
+// setVoxel call counter.
+__global__ __launch_bounds__(256) void k_bbox(const float* __restrict__ verts, uint64_t nverts, unsigned long long* state, float* out6,
+                                              unsigned long long* zero64)
 {
     unsigned long long mn[3] = {~0ull, ~0ull, ~0ull}, mx[3] = {0ull, 0ull, 0ull};
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nverts; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -93,6 +104,7 @@ __global__ __launch_bounds__(256) void k_bbox(const float* __restrict__ verts, u
     }
     // one set of atomics per workgroup (every wave hitting the same six addresses serialises: 147 us -> a few us)
     __shared__ unsigned long long red[4][6];
+    __shared__ int last_s;
     const int wv = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
@@ -106,26 +118,39 @@ __global__ __launch_bounds__(256) void k_bbox(const float* __restrict__ verts, u
             const unsigned long long o = red[w][a];
             v = a < 3 ? (o < v ? o : v) : (o > v ? o : v);
         }
-        if (a < 3) atomicMin(&keys[a], v); else atomicMax(&keys[a], v);
+        if (a < 3) atomicMin(&state[a], v); else atomicMax(&state[a], v);
     }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last_s = atomicAdd(&state[6], 1ull) == (unsigned long long)gridDim.x - 1ull;
+    __syncthreads();
+    if (!last_s) return;
+    __threadfence();
+    if (threadIdx.x < 6) {
+        const int a = threadIdx.x;
+        const unsigned long long key = __hip_atomic_load(&state[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (nverts == 0) {
+            out6[a] = a < 3 ? INFINITY : -INFINITY;
+        } else {
+            const unsigned low = (unsigned)key;
+            const unsigned idx = a < 3 ? low : 0xFFFFFFFFu - low;
+            out6[a] = verts[3 * (uint64_t)idx + (a % 3)];
+        }
+        __hip_atomic_store(&state[a], a < 3 ? ~0ull : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x == 6) __hip_atomic_store(&state[6], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 7 && zero64) *zero64 = 0ull;
 }
 
-__global__ void k_bbox_finish(const float* __restrict__ verts, uint64_t nverts, const unsigned long long* keys, float* out6)
+void bbox_state_init(unsigned long long state7[7])
 {
-    const int a = threadIdx.x;
-    if (a >= 6) return;
-    if (nverts == 0) { out6[a] = a < 3 ? INFINITY : -INFINITY; return; }
-    const unsigned low = (unsigned)keys[a];
-    const unsigned idx = a < 3 ? low : 0xFFFFFFFFu - low;
-    out6[a] = verts[3 * (uint64_t)idx + (a % 3)];
+    for (int a = 0; a < 3; ++a) { state7[a] = ~0ull; state7[3 + a] = 0ull; }
+    state7[6] = 0ull;
 }
 
-void launch_bbox(const float* verts, uint64_t nverts, unsigned long long* keys6, float* out6, hipStream_t s)
+void launch_bbox(const float* verts, uint64_t nverts, unsigned long long* state7, float* out6, unsigned long long* zero64, hipStream_t s)
 {
-    static const unsigned long long init[6] = {~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull};
-    hipMemcpyAsync(keys6, init, sizeof(init), hipMemcpyHostToDevice, s);
-    if (nverts) VX_KL(k_bbox, dim3(grid_for(nverts, 256 * 4, 512)), dim3(256), 0, s, verts, nverts, keys6);
-    VX_KL(k_bbox_finish, dim3(1), dim3(64), 0, s, verts, nverts, keys6, out6);
+    VX_KL(k_bbox, dim3(nverts ? grid_for(nverts, 256 * 4, 512) : 1u), dim3(256), 0, s, verts, nverts, state7, out6, zero64);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -231,13 +256,137 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_apply(const uint32_t* __res
     }
 }
 
-size_t scan_tmp_bytes(uint64_t n) { return (size_t)(((n + 1) + kScanTile - 1) / kScanTile + 1) * sizeof(unsigned long long); }
+// Single-pass variant (decoupled look-back): one kernel instead of three.  Tiles are handed out by a ticket counter so that
+// every tile a block waits for has already started; a tile publishes (flag | value) in ONE 64-bit word -- flag 1: the tile's
+// own sum ("aggregate"), flag 2: the sum of everything up to and including the tile ("prefix") -- and wave 0 of the block
+// walks back over its predecessors' words, 64 at a time, until it meets a prefix.  Values are carried in 62 bits.
+// Flag and value travel in the same word, so relaxed agent-scope atomics are enough (acquire/release would add a cache
+// invalidate / write-back to every poll: measured 190 us per scan instead of 40).
+constexpr unsigned long long kScanFlagA = 1ull << 62, kScanFlagP = 2ull << 62, kScanValMask = (1ull << 62) - 1ull;
+
+// Large tiles (1024 threads x 16 elements): a 4M-element scan is 256 tiles, so the look-back chain is a handful of hops
+// (with 2048-element tiles the chain of 2048 hops at cross-XCD atomic latency cost as much as the three-pass scan).
+constexpr int kOneBlock = 1024, kOneItems = 16, kOneTile = kOneBlock * kOneItems;
+
+template <bool POPC>
+__global__ __launch_bounds__(kOneBlock) void k_scan_onepass(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t n,
+                                                           unsigned long long* status /*[0]: ticket, [1]: finished tiles, [2 + tile]: state*/, uint32_t ntiles,
+                                                           unsigned long long* total)
+{
+    __shared__ unsigned wsum[kOneBlock / 64];
+    __shared__ unsigned tile_s;
+    __shared__ unsigned long long prefix_s;
+    if (threadIdx.x == 0) tile_s = (unsigned)atomicAdd(status, 1ull);
+    __syncthreads();
+    const unsigned tile = tile_s;
+    unsigned long long* st = status + 2;
+    const uint64_t base = (uint64_t)tile * kOneTile + (uint64_t)threadIdx.x * kOneItems;
+    unsigned v[kOneItems];
+    const bool full = base + kOneItems <= n;
+    if (full) {
+#pragma unroll
+        for (int q = 0; q < kOneItems / 4; ++q) {
+            const uint4 a = *reinterpret_cast<const uint4*>(in + base + 4 * q);
+            v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
+        }
+        if (POPC) {
+#pragma unroll
+            for (int j = 0; j < kOneItems; ++j) v[j] = (unsigned)__popc(v[j]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kOneItems; ++j) v[j] = scan_ld<POPC>(in, base + j, n);
+    }
+    unsigned tsum = 0;
+#pragma unroll
+    for (int j = 0; j < kOneItems; ++j) tsum += v[j];
+    // exclusive scan of the thread sums over the block
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned inc = tsum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    unsigned wbase = 0, btot = 0;
+#pragma unroll
+    for (int w = 0; w < kOneBlock / 64; ++w) {
+        const unsigned x = wsum[w];
+        if (w < wv) wbase += x;
+        btot += x;
+    }
+    unsigned pre = wbase + inc - tsum;
+    if (threadIdx.x < 64) {
+        unsigned long long excl = 0;
+        if (tile == 0) {
+            if (lane == 0) __hip_atomic_store(&st[0], kScanFlagP | (unsigned long long)btot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0) __hip_atomic_store(&st[tile], kScanFlagA | (unsigned long long)btot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            long long look = (long long)tile - 1;
+            for (;;) {
+                const long long idx = look - lane;
+                unsigned long long w;
+                do {  // every predecessor in the window has at least started (ticket order): wait for its first word
+                    w = idx >= 0 ? __hip_atomic_load(&st[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kScanFlagP;
+                } while (__ballot((w >> 62) == 0ull));
+                const unsigned long long pm = __ballot((w >> 62) == 2ull);
+                const int first_p = pm ? __ffsll((long long)pm) - 1 : 64;
+                excl += wave_sum_u64(lane <= first_p ? (w & kScanValMask) : 0ull);
+                if (pm) break;
+                look -= 64;
+            }
+            if (lane == 0) __hip_atomic_store(&st[tile], kScanFlagP | (excl + (unsigned long long)btot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) {
+            prefix_s = excl;
+            if (tile == ntiles - 1 && total) *total = excl + (unsigned long long)btot;
+        }
+        // self-cleaning: the tile that finishes its look-back last (nobody reads a state word any more) zeroes the ticket, the
+        // counter and every state word, so the next scan on this buffer needs no memset
+        unsigned long long fin = 0;
+        if (lane == 0) fin = atomicAdd(&status[1], 1ull);
+        fin = shfl_u64_k(fin, 0);
+        if (fin == (unsigned long long)ntiles - 1ull) {
+            for (uint32_t i = lane; i < ntiles + 2u; i += 64u) __hip_atomic_store(&status[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    pre += (unsigned)prefix_s;
+    if (full) {  // all outputs of this thread exist (out has n + 1 entries)
+#pragma unroll
+        for (int q = 0; q < kOneItems / 4; ++q) {
+            uint4 a;
+            a.x = pre; pre += v[4 * q]; a.y = pre; pre += v[4 * q + 1]; a.z = pre; pre += v[4 * q + 2]; a.w = pre; pre += v[4 * q + 3];
+            *reinterpret_cast<uint4*>(out + base + 4 * q) = a;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kOneItems; ++j) {
+            if (base + j <= n) out[base + j] = pre;
+            pre += v[j];
+        }
+    }
+}
+
+size_t scan_tmp_bytes(uint64_t n) { return (size_t)(((n + 1) + kScanTile - 1) / kScanTile + 4) * sizeof(unsigned long long); }
 
 void launch_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, bool popcount_input, void* tmp, unsigned long long* total64,
-                     hipStream_t s)
+                     hipStream_t s, bool tmp_is_zero)
 {
     const uint32_t nblocks = (uint32_t)(((n + 1) + kScanTile - 1) / kScanTile);
-    unsigned long long* sums = (unsigned long long*)tmp;
+    unsigned long long* status = (unsigned long long*)tmp;
+    static const bool three_pass = getenv("VOXHIP_SCAN_3PASS") && atoi(getenv("VOXHIP_SCAN_3PASS"));
+    const bool aligned = ((((uintptr_t)in) | ((uintptr_t)out)) & 15u) == 0;  // the single-pass kernel moves 16-byte vectors
+    if (!three_pass && aligned) {
+        const uint32_t ntiles = (uint32_t)(((n + 1) + kOneTile - 1) / kOneTile);
+        if (!tmp_is_zero) (void)hipMemsetAsync(status, 0, (size_t)(ntiles + 2) * sizeof(unsigned long long), s);
+        if (popcount_input) VX_KL(k_scan_onepass<true>, dim3(ntiles), dim3(kOneBlock), 0, s, in, out, n, status, ntiles, total64);
+        else VX_KL(k_scan_onepass<false>, dim3(ntiles), dim3(kOneBlock), 0, s, in, out, n, status, ntiles, total64);
+        return;
+    }
+    unsigned long long* sums = status;
     if (popcount_input) {
         VX_KL(k_scan_sums<true>, dim3(nblocks), dim3(kScanBlock), 0, s, in, n, sums);
         VX_KL(k_scan_spine, dim3(1), dim3(1024), 0, s, sums, nblocks, total64);
@@ -247,6 +396,7 @@ void launch_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, bool popcoun
         VX_KL(k_scan_spine, dim3(1), dim3(1024), 0, s, sums, nblocks, total64);
         VX_KL(k_scan_apply<false>, dim3(nblocks), dim3(kScanBlock), 0, s, in, out, n, sums);
     }
+    if (tmp_is_zero) (void)hipMemsetAsync(status, 0, scan_tmp_bytes(n), s);  // keep the caller's "zero between scans" contract
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -653,46 +803,5 @@ void launch_emit_morton_aabbs(const uint64_t* items, uint64_t n, const float roo
 
 __global__ void k_set_bit(uint32_t* words, uint64_t idx) { atomicOr(&words[idx >> 5], 1u << (idx & 31)); }
 void launch_set_bit(uint32_t* words, uint64_t idx, hipStream_t s) { VX_KL(k_set_bit, dim3(1), dim3(1), 0, s, words, idx); }
-
-// ------------------------------------------------------------------------------------------------------------
-// Occupancy mip (one bit per 8^3 cells of the level below) for empty-space skipping in K6 (vx_trace.hip).
-// ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_build_coarse(const uint32_t* __restrict__ words, uint32_t fx, uint32_t fy, uint32_t fz, uint32_t cx,
-                                                      uint32_t cy, uint32_t cz, uint32_t* __restrict__ cwords)
-{
-    struct { uint32_t dim[3]; } g = {{fx, fy, fz}};
-    const uint64_t ncoarse = (uint64_t)cx * cy * cz;
-    for (uint64_t c = (uint64_t)blockIdx.x * 256u + threadIdx.x; c < ncoarse; c += (uint64_t)gridDim.x * 256u) {
-        const uint32_t kz = (uint32_t)(c / ((uint64_t)cx * cy));
-        const uint32_t rem = (uint32_t)(c - (uint64_t)kz * cx * cy);
-        const uint32_t ky = rem / cx, kx = rem - ky * cx;
-        const uint32_t x0 = kx * kCoarse;
-        const uint32_t nb = (g.dim[0] - x0) < kCoarse ? (g.dim[0] - x0) : kCoarse;
-        uint32_t any = 0;
-        for (uint32_t fz = 0; fz < kCoarse; ++fz) {
-            const uint32_t z = kz * kCoarse + fz;
-            if (z >= g.dim[2]) break;
-            for (uint32_t fy = 0; fy < kCoarse; ++fy) {
-                const uint32_t y = ky * kCoarse + fy;
-                if (y >= g.dim[1]) break;
-                const uint64_t i0 = (uint64_t)g.dim[0] * ((uint64_t)y + (uint64_t)g.dim[1] * z) + x0;
-                const uint32_t sh = (uint32_t)i0 & 31u;
-                const uint64_t wi = i0 >> 5;
-                uint32_t val = words[wi] >> sh;
-                if (sh + nb > 32u) val |= words[wi + 1] << (32u - sh);
-                any |= val & ((1u << nb) - 1u);
-            }
-        }
-        if (any) atomicOr(&cwords[c >> 5], 1u << (c & 31));
-    }
-}
-
-void launch_build_coarse(const uint32_t* words, const uint32_t fdim[3], const uint32_t cdim[3], uint32_t* cwords, hipStream_t s)
-{
-    const uint64_t nc = (uint64_t)cdim[0] * cdim[1] * cdim[2];
-    if (!nc) return;
-    hipMemsetAsync(cwords, 0, (size_t)((nc + 31) / 32) * 4, s);
-    VX_KL(k_build_coarse, dim3(grid_for(nc, 256, kMaxBlocks)), dim3(256), 0, s, words, fdim[0], fdim[1], fdim[2], cdim[0], cdim[1], cdim[2], cwords);
-}
 
 }  // namespace vx

@@ -139,6 +139,49 @@ void launch_brick_bounds(const unsigned long long* bricks, uint64_t nbricks, uin
     VX_KL(k_brick_bounds, dim3((unsigned)nblk), dim3(256), 0, s, bricks, nbricks, bounds, m1);
 }
 
+// Level-2 mip: one bit per 8x8x8 bricks.  One workgroup per OUTPUT WORD (32 blocks: 16 waves x 2), one lane per (y, z) row of
+// a block's bricks: eight level-1 bits per lane, a ballot per block, one plain store per word -- no atomics, no memset.
+__global__ __launch_bounds__(1024) void k_build_mip2(const uint32_t* __restrict__ m1, uint32_t d1x, uint32_t d1y, uint32_t d1z, uint32_t d2x, uint32_t d2y,
+                                                     uint32_t d2z, uint32_t* __restrict__ m2)
+{
+    __shared__ uint32_t bits_s;
+    if (threadIdx.x == 0) bits_s = 0u;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint64_t n2 = (uint64_t)d2x * d2y * d2z;
+    uint32_t mine = 0u;
+    for (uint32_t k = 0; k < 2u; ++k) {
+        const uint32_t bit = wv * 2u + k;
+        const uint64_t c = (uint64_t)blockIdx.x * 32u + bit;
+        bool any = false;
+        if (c < n2) {
+            const uint32_t kz = (uint32_t)(c / ((uint64_t)d2x * d2y));
+            const uint32_t rem = (uint32_t)(c - (uint64_t)kz * d2x * d2y);
+            const uint32_t ky = rem / d2x, kx = rem - ky * d2x;
+            const uint32_t by = ky * 8u + (lane & 7u), bz = kz * 8u + (lane >> 3), bx0 = kx * 8u;
+            if (by < d1y && bz < d1z) {
+                const uint32_t nb = d1x - bx0 < 8u ? d1x - bx0 : 8u;
+                const uint64_t i0 = (uint64_t)bx0 + (uint64_t)d1x * ((uint64_t)by + (uint64_t)d1y * bz);
+                const uint32_t sh = (uint32_t)i0 & 31u;
+                uint32_t val = m1[i0 >> 5] >> sh;
+                if (sh + nb > 32u) val |= m1[(i0 >> 5) + 1] << (32u - sh);
+                any = (val & ((1u << nb) - 1u)) != 0u;
+            }
+        }
+        if (__ballot(any)) mine |= 1u << bit;
+    }
+    if (lane == 0u && mine) atomicOr(&bits_s, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) m2[blockIdx.x] = bits_s;
+}
+
+void launch_build_mip2(const uint32_t* m1, const uint32_t d1[3], const uint32_t d2[3], uint32_t* m2, hipStream_t s)
+{
+    const uint64_t n2 = (uint64_t)d2[0] * d2[1] * d2[2];
+    if (!n2) return;
+    VX_KL(k_build_mip2, dim3((unsigned)((n2 + 31) / 32)), dim3(1024), 0, s, m1, d1[0], d1[1], d1[2], d2[0], d2[1], d2[2], m2);
+}
+
 namespace {
 
 // everything a lane carries for the ray it is currently tracing
