@@ -596,6 +596,8 @@ __global__ __launch_bounds__(256) void k_voxelize(const TriRec* __restrict__ rec
         const SatRow row = sat_row_setup<EPS>(r.v, cy, cz, g.half);
         uint32_t mask = 0;
         if (row.alive) {
+            // (a two-sweep form -- box x + plane on every voxel, the six edge axes on the survivors only -- is slower: the
+            // wave pays for its lane with the most survivors, 0.21 ms vs 0.18 ms)
             for (uint32_t x = w.x0; x < w.x1; ++x) {
                 const float cx = cell_centre(g.org[0], g.vs, x);
                 if (sat_row_test<EPS>(row, r.v, cx, g.half)) mask |= 1u << (x & 31u);

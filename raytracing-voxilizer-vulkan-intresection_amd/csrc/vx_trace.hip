@@ -339,8 +339,17 @@ __device__ __forceinline__ bool setup_ray(Lane& R, const GridParams& g, const Tr
 // the exact rint formula.  Every range is dilated by the position tolerance, so the tested set is a superset of the cells
 // the reference's float boxes could report; the slab formula is the arbiter.  A ray skimming along an occupied wall for a
 // whole brick costs a few row tests here instead of ~15 generic DDA steps (the tail of the step histogram: 1203 steps).
+#ifdef VX_TRACE_DEBUG_UTIL
+#define VX_BT_COUNT(i) ++bt_cnt[i];
+#else
+#define VX_BT_COUNT(i)
+#endif
 __device__ __forceinline__ void brick_test(Lane& R, const GridParams& g, const TraceMips& M, float inv_vs, float tolp, int bx, int by, int bz, float tmin,
-                                           float tmax)
+                                           float tmax
+#ifdef VX_TRACE_DEBUG_UTIL
+                                           , int* bt_cnt  // [0] slices entered, [1] rows tested, [2] exact slab tests, [3] calls past the culling
+#endif
+)
 {
     const float vs = g.vs;
     const int fx = bx * 8, fy = by * 8, fz = bz * 8;
@@ -379,6 +388,7 @@ __device__ __forceinline__ void brick_test(Lane& R, const GridParams& g, const T
     s1 = s1 > ozmax ? ozmax : s1;
     if (s0 > s1) return;
     const unsigned long long* bp = M.bricks + (size_t)bidx * 8u;
+    VX_BT_COUNT(3)
     const float o3[3] = {R.ox, R.oy, R.oz}, inv3[3] = {R.ix, R.iy, R.iz};
     const bool zfwd = R.dz >= 0.0f;
     for (int k = 0; k <= s1 - s0; ++k) {
@@ -392,6 +402,7 @@ __device__ __forceinline__ void brick_test(Lane& R, const GridParams& g, const T
             tsb = fminf(tsb, zd ? INFINITY : fmaxf(t1, t2));
         }
         if (!(tsa <= tsb)) continue;
+        VX_BT_COUNT(0)
         const unsigned long long bits = bp[s];
         if (bits) {
             const float ya = R.oy + tsa * R.dy, yb = R.oy + tsb * R.dy;
@@ -401,6 +412,7 @@ __device__ __forceinline__ void brick_test(Lane& R, const GridParams& g, const T
             for (int r = r0; r <= r1; ++r) {
                 const uint32_t rowbits = (uint32_t)(bits >> (8 * r)) & 0xFFu;
                 if (!rowbits) continue;
+                VX_BT_COUNT(1)
                 float tra = tsa, trb = tsb;
                 {
                     const float pl = g.org[1] + (float)(fy + r) * vs, ph = g.org[1] + (float)(fy + r + 1) * vs;
@@ -419,6 +431,7 @@ __device__ __forceinline__ void brick_test(Lane& R, const GridParams& g, const T
                 while (cand) {
                     const int b = __ffs(cand) - 1;
                     cand &= cand - 1;
+                    VX_BT_COUNT(2)
                     const uint32_t x = (uint32_t)(fx + b), y = (uint32_t)(fy + r), z = (uint32_t)(fz + s);
                     float bb[6];
                     cell_aabb(g, x, y, z, bb);
@@ -481,9 +494,10 @@ __device__ __forceinline__ bool upper_step(Lane& R, const GridParams& g, const T
                 const uint32_t i = (uint32_t)nx + M.d1[0] * ((uint32_t)ny + M.d1[1] * (uint32_t)nz);
                 const uint32_t w = LDS_M1 ? m1_lds[i >> 5] : M.w1[i >> 5];
                 if ((w >> (i & 31u)) & 1u) {
+                    // post the brick; with nothing else to look at in this cell the walk moves on in the same step (the
+                    // brick test runs before the lane's next step, and testing a brick late only delays the ray's end)
                     R.pending = true;
                     R.bx = nx; R.by = ny; R.bz = nz;
-                    return true;
                 }
             }
         } else {
@@ -507,7 +521,6 @@ __device__ __forceinline__ bool upper_step(Lane& R, const GridParams& g, const T
     if (!desc && !(t_o <= fminf(R.tf, R.best + R.tau_term))) return false;
     int ncx = R.cx, ncy = R.cy, ncz = R.cz, nl = lvl;
     float t_new = t_o;
-    bool pop = false;
     if (desc) {
         // into the NOMINAL block's bricks, starting exactly at its entry time (a time slack would slide the start point
         // along the ray's major axis; the start cell's rounding is covered by the brick walk's probes)
@@ -527,9 +540,15 @@ __device__ __forceinline__ bool upper_step(Lane& R, const GridParams& g, const T
         const int hi_a = lvl == 2 ? top_hi : p_a * 8 + 8;
         if (c_a < lo_a || c_a >= hi_a) {
             if (lvl == 2) return false;  // left the grid (and its halo)
-            // left the block: back to the block level; the block itself has been visited, it only advances next
-            pop = true;
-            ncx = R.px; ncy = R.py; ncz = R.pz;
+            // Left the block -- through a face that is also the BLOCK's exit face: the plane is the same fine index at both
+            // levels, so the block's own exit time is this t_o and its exit axis this axis (the other axes' block planes lie at
+            // or behind the brick planes, and ties resolve by the same x, y, z priority).  So the block advances right here,
+            // instead of popping to the block level and spending a step on "visited, advance".
+            const int q_a = p_a + s_a;
+            if (q_a < -1 || q_a >= top_hi) return false;
+            ncx = ex ? q_a : R.px;
+            ncy = ey ? q_a : R.py;
+            ncz = (!ex && !ey) ? q_a : R.pz;
             nl = 2;
         } else {
             ncx = ex ? c_a : ncx;
@@ -546,7 +565,7 @@ __device__ __forceinline__ bool upper_step(Lane& R, const GridParams& g, const T
     R.t_in = t_new;
     R.emask = desc ? 0 : (ex ? 1 : (ey ? 2 : 4));
     R.tau_ent = desc ? 0.0f : sel3(ex, ey, R.taux, R.tauy, R.tauz);
-    R.fresh = !pop;
+    R.fresh = true;
     R.todo = 0u;
     R.occ = false;
     return true;
@@ -622,7 +641,7 @@ __device__ __forceinline__ ColdPtr cold_params()
 // diagnostic build: where the wave cycles go.  [0..4] cycles in refill / donate / walk / brick test / retire,
 // [5] walk iterations, [6] sum of active lanes over them, [7] brick phases, [8] sum of lanes with a pending brick,
 // [9] rounds, [10] sum of busy lanes at round start
-__device__ unsigned long long g_trace_util[16];
+__device__ unsigned long long g_trace_util[24];
 #define VX_UTIL_T(i) { const unsigned long long now_ = __builtin_readcyclecounter(); dbg_c[i] += now_ - dbg_last; dbg_last = now_; }
 #define VX_UTIL_ADD(i, v) dbg_c[i] += (unsigned long long)(v);
 #else
@@ -663,7 +682,9 @@ __global__ __launch_bounds__(256) void k_trace(const TraceParams P)
     int dbg_steps = 0;
 #endif
 #ifdef VX_TRACE_DEBUG_UTIL
-    unsigned long long dbg_c[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long dbg_c[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int bt_tot[4] = {0, 0, 0, 0};
+    int bt_work = 0;
     unsigned long long dbg_last = __builtin_readcyclecounter();
 #endif
 #ifdef VX_TRACE_DEBUG_CYCLES
@@ -814,11 +835,29 @@ __global__ __launch_bounds__(256) void k_trace(const TraceParams P)
             VX_UTIL_ADD(7, 1)
             VX_UTIL_ADD(8, __popcll(pm))
             if (pend) {
+#ifdef VX_TRACE_DEBUG_UTIL
+                int bt_cnt[4] = {0, 0, 0, 0};
+                brick_test(R, g, M, inv_vs, R.tolp, R.bx, R.by, R.bz, P.hot.tmin, R.tmax, bt_cnt);
+                bt_tot[0] += bt_cnt[0]; bt_tot[1] += bt_cnt[1]; bt_tot[2] += bt_cnt[2]; bt_tot[3] += bt_cnt[3];
+                bt_work = bt_cnt[0] * 20 + bt_cnt[1] * 40 + bt_cnt[2] * 60;
+#else
                 brick_test(R, g, M, inv_vs, R.tolp, R.bx, R.by, R.bz, P.hot.tmin, R.tmax);
+#endif
                 R.pending = false;
                 // shadow query (gl_RayFlagsTerminateOnFirstHitEXT, raytrace2.rchit:108): any accepted hit ends the ray
                 if (P.hot.any_hit && R.best_idx != ~0ull) finished = true;
+                // the walk already stands in the next cell (entered at t_in = the exit time of the brick's cell): apply the
+                // walk's termination rule with the new best now instead of spending a step on it
+                if (R.fresh && R.emask != 0 && !(R.t_in <= fminf(R.tf, R.best + R.tau_term))) finished = true;
             }
+#ifdef VX_TRACE_DEBUG_UTIL
+            {   // divergence of the brick phase: the wave pays the slowest lane's work
+                int mx = pend ? bt_work : 0, sm = pend ? bt_work : 0;
+                for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(mx, m, 64); mx = o > mx ? o : mx; sm += __shfl_xor(sm, m, 64); }
+                dbg_c[11] += (unsigned long long)mx;
+                dbg_c[12] += (unsigned long long)sm;
+            }
+#endif
             VX_UTIL_T(3)
         }
         VX_UTIL_T(2)
@@ -851,17 +890,22 @@ __global__ __launch_bounds__(256) void k_trace(const TraceParams P)
         VX_UTIL_T(4)
     }
 #ifdef VX_TRACE_DEBUG_UTIL
+    for (int i = 0; i < 4; ++i) {
+        int v = bt_tot[i];
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        if (lane == 0) atomicAdd(&g_trace_util[16 + i], (unsigned long long)v);
+    }
     if (lane == 0)
-        for (int i = 0; i < 11; ++i) atomicAdd(&g_trace_util[i], dbg_c[i]);
+        for (int i = 0; i < 13; ++i) atomicAdd(&g_trace_util[i], dbg_c[i]);
 #endif
 }
 
 #ifdef VX_TRACE_DEBUG_UTIL
 }  // namespace vx
-extern "C" int vx_debug_trace_util(unsigned long long* out16, int reset)
+extern "C" int vx_debug_trace_util(unsigned long long* out24, int reset)
 {
-    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(vx::g_trace_util), 16 * 8) != hipSuccess) return 1;
-    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(vx::g_trace_util), z, 16 * 8) != hipSuccess) return 1; }
+    if (out24 && hipMemcpyFromSymbol(out24, HIP_SYMBOL(vx::g_trace_util), 24 * 8) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[24] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(vx::g_trace_util), z, 24 * 8) != hipSuccess) return 1; }
     return 0;
 }
 namespace vx {

@@ -10,7 +10,7 @@ rays = torch.from_numpy(vx_scenes.random_rays(n, v.min(0), v.max(0), seed=2)).cu
 d_t = torch.empty(n, dtype=torch.float32, device="cuda"); d_p = torch.empty(n, dtype=torch.int32, device="cuda")
 g.trace_device(rays.data_ptr(), n, d_t.data_ptr(), d_p.data_ptr()); torch.cuda.synchronize()
 L = voxhip.lib()
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 24)()
 L.vx_debug_trace_util(out, 1)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
@@ -28,4 +28,5 @@ print("walk iterations %d, mean active lanes %.1f" % (o[5], o[6] / max(o[5], 1))
 print("brick phases    %d, mean lanes with a brick %.1f" % (o[7], o[8] / max(o[7], 1)))
 print("rounds          %d, mean busy lanes %.1f" % (o[9], o[10] / max(o[9], 1)))
 print("cycles per walk iteration %.0f, per brick phase %.0f" % (o[2] / max(o[5], 1), o[3] / max(o[7], 1)))
-print("wave lifetime cycles: mean %.3g  min %.3g  max %.3g ; kernel span (first in -> last out) %.3g cycles" % (tot / 4096.0, o[12], o[11], o[13] - o[14]))
+print("brick tests: %d past culling of %d; per test past culling: %.2f slices, %.2f rows, %.2f slab tests" % (o[19], o[8], o[16] / max(o[19], 1), o[17] / max(o[19], 1), o[18] / max(o[19], 1)))
+print("brick phase divergence: slowest lane's work / mean work of the lanes with a brick = %.2f" % (o[11] / max(o[12] / max(o[8] / max(o[7], 1), 1), 1)))
