@@ -210,6 +210,8 @@ struct Lane {
     bool occ;                                  // level 2: the block or a probed neighbour holds something
     bool pending;                              // level 1: an occupied brick waits for its brick test
     int bx, by, bz;                            // that brick
+    uint32_t ob;                               // its occupied-cell bounds, loaded when the brick is posted
+    uint32_t pf;                               // first word of its slices, loaded at the same time only to pull the line in
 };
 
 // Axis selection BY VALUE.  `c ? R.x : R.y` on two struct members is an lvalue conditional: clang selects the ADDRESS and
@@ -325,6 +327,8 @@ __device__ __forceinline__ bool setup_ray(Lane& R, const GridParams& g, const Tr
     R.occ = false;
     R.pending = false;
     R.bx = R.by = R.bz = 0;
+    R.ob = 0u;
+    R.pf = 0u;
     R.px = R.py = R.pz = 0;
     if (miss || !(tn <= tf) || !g.nvox) return false;
     // one virtual cell of halo around the top level: a ray sliding along the outside of a boundary face within tolerance
@@ -374,7 +378,7 @@ __device__ __forceinline__ void brick_test(Lane& R, const GridParams& g, const T
     const float tol2 = 2.0f * tolp;  // positions derived from a time carry the time's error as well
     const uint32_t bidx = (uint32_t)bx + M.d1[0] * ((uint32_t)by + M.d1[1] * (uint32_t)bz);
     // the (dilated) cell box of the ray segment inside the brick against the box of the brick's occupied cells
-    const uint32_t ob = M.bounds[bidx];
+    const uint32_t ob = R.ob;
     const int oxmin = ob & 7u, oxmax = (ob >> 3) & 7u, oymin = (ob >> 6) & 7u, oymax = (ob >> 9) & 7u, ozmin = (ob >> 12) & 7u, ozmax = (ob >> 15) & 7u;
     const float xa0 = R.ox + ta * R.dx, xb0 = R.ox + tb * R.dx;
     const int cb0 = (int)floorf((fminf(xa0, xb0) - tol2 - lox) * inv_vs), cb1 = (int)floorf((fmaxf(xa0, xb0) + tol2 - lox) * inv_vs);
@@ -498,6 +502,10 @@ __device__ __forceinline__ bool upper_step(Lane& R, const GridParams& g, const T
                     // brick test runs before the lane's next step, and testing a brick late only delays the ray's end)
                     R.pending = true;
                     R.bx = nx; R.by = ny; R.bz = nz;
+                    // start the brick's two dependent loads now: incoherent rays miss L2 on nearly every brick (16 MiB of
+                    // slices at 512^3), and with four waves per SIMD that latency is not hidden inside the brick phase
+                    R.ob = M.bounds[i];
+                    R.pf = reinterpret_cast<const uint32_t*>(M.bricks)[(size_t)i * 16u];
                 }
             }
         } else {
@@ -653,7 +661,7 @@ __device__ unsigned long long g_trace_util[24];
 // refill possible) and every lane's ray (or piece of a ray) has finished; each finishes in a bounded number of steps, and a
 // piece is only split while its t interval is longer than six bricks.
 template <bool LDS_M1>
-__global__ __launch_bounds__(256) void k_trace(const TraceParams P)
+__global__ __launch_bounds__(256, 4 /*waves per SIMD: keeps the allocation at <= 128 VGPRs*/) void k_trace(const TraceParams P)
 {
     constexpr int kStepsPerRound = 4;   // upper-level steps between two brick-test phases
     constexpr int kItersPerRound = 2;   // (walk, brick test) iterations between two refill checks
@@ -835,6 +843,7 @@ __global__ __launch_bounds__(256) void k_trace(const TraceParams P)
             VX_UTIL_ADD(7, 1)
             VX_UTIL_ADD(8, __popcll(pm))
             if (pend) {
+                asm volatile("" ::"v"(R.pf));  // the prefetching load has to be "used"
 #ifdef VX_TRACE_DEBUG_UTIL
                 int bt_cnt[4] = {0, 0, 0, 0};
                 brick_test(R, g, M, inv_vs, R.tolp, R.bx, R.by, R.bz, P.hot.tmin, R.tmax, bt_cnt);
@@ -999,9 +1008,12 @@ void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* wo
     const uint32_t m1_words = (uint32_t)((n1 + 31) / 32);
     const bool lds_m1 = (size_t)m1_words * 4 <= 40960;  // 4 workgroups x 40 KiB fit the CU's 160 KiB
     // persistent grid: 256 CUs x 4 resident 256-thread workgroups, fewer when there are not that many rays
-    static const int env_blocks = getenv("VOXHIP_TRACE_BLOCKS") ? atoi(getenv("VOXHIP_TRACE_BLOCKS")) : 1024;
+    // Small batches (a few rays per lane) are bound by the drain of their longest rays and run faster on three waves per SIMD
+    // than on four (1M rays: 0.50 ms at 768 workgroups, 0.54 ms at 1024; equal at 2M; 8M: 2.32 vs 2.12 ms).
+    static const int env_blocks = getenv("VOXHIP_TRACE_BLOCKS") ? atoi(getenv("VOXHIP_TRACE_BLOCKS")) : 0;
+    const uint64_t max_blocks = env_blocks > 0 ? (uint64_t)env_blocks : (nrays <= 1500000ull ? 768ull : 1024ull);
     uint64_t nblk = (nrays + 255) / 256;
-    if (nblk > (uint64_t)env_blocks) nblk = (uint64_t)env_blocks;
+    if (nblk > max_blocks) nblk = max_blocks;
     const dim3 grid((unsigned)nblk), block(256);
     const bool want_rank = (io.prim_out || io.hits || io.normal_out) && word_prefix && idx_tmp && io.t_out;
     unsigned long long* idx_out = want_rank ? idx_tmp : nullptr;
