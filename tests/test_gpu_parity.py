@@ -356,6 +356,62 @@ def test_revoxelize_reuses_handle(gpu):
     assert np.array_equal(g.bitmask(), a)       # idempotent
 
 
+def test_handle_reuse_sequence(gpu):
+    """One handle through a sequence of rebuilds of different meshes / sizes / shards, queries in varying order.
+
+    The handle keeps self-cleaning device state between builds (bbox reduction, scan status words), counts arrive through a
+    pinned-host mailbox, and the traversal structures + word prefix are queued eagerly behind an unsharded build: every
+    rebuild has to start from a clean state and every query has to see the build it follows."""
+    scenes = [("rotcube", 0.09), ("soup2000", 0.02), ("cube", 0.2), ("blob70k", 2.0 / 64), ("cube", 0.0625), ("adversarial", 0.1), ("soup2000", 0.031)]
+    g = None
+    for k, (name, vs) in enumerate(scenes):
+        v, t = vx_scenes.scene(name)
+        vs = np.float32(vs)
+        mesh = gpu.Mesh.from_arrays(v, t)
+        if g is None:
+            g = gpu.Grid.voxelize(mesh, vs, gpu.GRID_VEC)
+        elif k % 3 == 2:
+            # two word shards into the same handle, OR-ed on the host (no eager structures: the mask is incomplete)
+            nwords = (int(np.prod(oracle.grid_info(v, vs)["dim"])) + 31) // 32
+            parts = []
+            for r in range(2):
+                wb, we, _ = gpu.shard_words(nwords, r, 2)
+                g.revoxelize(mesh, vs, words=(wb, we))
+                parts.append(g.bitmask().copy())
+            ow, _, gi = oracle.build_bool(v, t, vs)
+            assert np.array_equal(parts[0] | parts[1], ow)
+            continue
+        else:
+            g.revoxelize(mesh, vs)
+        ow, calls, gi = oracle.build_bool(v, t, vs)
+        oa = oracle.bool_aabbs(ow, gi, vs)
+        rays = vx_scenes.random_rays(3000, gi["bmin"], gi["bmax"], seed=10 + k)
+        if k % 2 == 0:   # trace first (needs bricks + prefix), then the lists and the counts
+            if len(oa):
+                check_trace(gpu, g, oa, rays)
+            assert np.array_equal(g.bitmask(), ow)
+            d = g.describe()
+        else:            # counts first
+            d = g.describe()
+            assert np.array_equal(g.bitmask(), ow)
+            if len(oa):
+                check_trace(gpu, g, oa, rays)
+        assert d["occupied"] == len(oa) and d["set_calls"] == calls and d["dim"] == gi["dim"]
+        ov = oracle.build_vec(v, t, vs)
+        assert g.aabbs().tobytes() == ov.tobytes()     # Vec flavour: ordered list with duplicates
+    # host-side setVoxel after a device build invalidates prefix / traversal structures
+    v, t = vx_scenes.scene("cube")
+    mesh = gpu.Mesh.from_arrays(v, t)
+    gb = gpu.Grid.voxelize(mesh, np.float32(0.25))
+    n0 = gb.describe()["occupied"]
+    free = np.flatnonzero(np.unpackbits(gb.bitmask().view(np.uint8), bitorder="little")[: int(np.prod(gb.describe()["dim"]))] == 0)
+    X, Y, Z = gb.describe()["dim"]
+    i = int(free[0])
+    gb.set_voxel(i % X, (i // X) % Y, i // (X * Y))
+    assert gb.describe()["occupied"] == n0 + 1
+    assert len(gb.aabbs()) == n0 + 1
+
+
 # ---------------------------------------------------------------------------------------------- randomised parity
 def test_random_soups_property(gpu):
     """Property test (seeded, the oracle is the checker): random triangle soups with random sizes, offsets (grid origins with
