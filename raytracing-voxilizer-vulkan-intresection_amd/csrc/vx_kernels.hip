@@ -404,6 +404,27 @@ void launch_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, bool popcoun
 // as the reference does, clamp it to this rank's z slab, and count work units.  A work unit is one row of the box
 // (fixed y, z) cut at multiples of 32 in x, i.e. at most one 32-voxel stretch that maps onto <= 2 bitmask words.
 // ------------------------------------------------------------------------------------------------------------
+// Exact trimming of a candidate range.  The reference's range (VoxelBuilder.hpp:175-184) carries a spare cell on the high
+// side of every axis (`+ 2`), i.e. slabs of voxels that its SAT then rejects by the box-axis test of that axis (:94-100).
+// That test depends only on the slab's index, so a slab for which it separates -- evaluated here with the very floats the
+// SAT uses (cell_centre, v - c, min3/max3 against half) -- cannot contain a hit and is dropped from the end of the range.
+// On the bench mesh this halves the candidate volume (4.2 x 4.7 x 4.7 -> 3.2 x 3.7 x 3.7 voxels per triangle).
+__device__ __forceinline__ void trim_axis(float a0, float a1, float a2, float org, float vs, float half, int& s, int& e)
+{
+    while (e > s) {
+        const float c = cell_centre(org, vs, (uint32_t)(e - 1));
+        const float p0 = a0 - c, p1 = a1 - c, p2 = a2 - c;
+        if (!((min3(p0, p1, p2) > half) || (max3(p0, p1, p2) < -half))) break;
+        --e;
+    }
+    while (e > s) {
+        const float c = cell_centre(org, vs, (uint32_t)s);
+        const float p0 = a0 - c, p1 = a1 - c, p2 = a2 - c;
+        if (!((min3(p0, p1, p2) > half) || (max3(p0, p1, p2) < -half))) break;
+        ++s;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_tri_setup(const float* __restrict__ verts, const int32_t* __restrict__ idx, uint64_t tri_begin,
                                                    uint32_t ntri, GridParams g, float vsize, uint32_t zlo, uint32_t zhi,
                                                    TriRec* __restrict__ recs, uint32_t* __restrict__ units)
@@ -425,6 +446,9 @@ __global__ __launch_bounds__(256) void k_tri_setup(const float* __restrict__ ver
     cand_axis(r.v[2], r.v[5], r.v[8], g.org[2], vsize, g.dim[2], zs, ze);
     zs = zs > (int)zlo ? zs : (int)zlo;
     ze = ze < (int)zhi ? ze : (int)zhi;
+    trim_axis(r.v[0], r.v[3], r.v[6], g.org[0], g.vs, g.half, xs, xe);
+    trim_axis(r.v[1], r.v[4], r.v[7], g.org[1], g.vs, g.half, ys, ye);
+    trim_axis(r.v[2], r.v[5], r.v[8], g.org[2], g.vs, g.half, zs, ze);
     const uint32_t nx = xe > xs ? (uint32_t)(xe - xs) : 0u;
     const uint32_t ny = ye > ys ? (uint32_t)(ye - ys) : 0u;
     const uint32_t nz = ze > zs ? (uint32_t)(ze - zs) : 0u;
