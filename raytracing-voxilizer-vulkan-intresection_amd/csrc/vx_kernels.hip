@@ -619,7 +619,11 @@ __global__ __launch_bounds__(256) void k_voxelize(const TriRec* __restrict__ rec
         const float cy = cell_centre(g.org[1], g.vs, w.y), cz = cell_centre(g.org[2], g.vs, w.z);
         const SatRow row = sat_row_setup<EPS>(r.v, cy, cz, g.half);
         uint32_t mask = 0;
+#ifdef VX_DIAG_NO_SAT
+        if (row.alive && w.x0 == 0xFFFFFFFFu) {
+#else
         if (row.alive) {
+#endif
             // (a two-sweep form -- box x + plane on every voxel, the six edge axes on the survivors only -- is slower: the
             // wave pays for its lane with the most survivors, 0.21 ms vs 0.18 ms)
             for (uint32_t x = w.x0; x < w.x1; ++x) {
@@ -643,7 +647,9 @@ __global__ __launch_bounds__(256) void k_voxelize(const TriRec* __restrict__ rec
         }
     });
     hits = wave_sum_u32(hits);
+#ifndef VX_DIAG_NO_SETCALLS
     if ((threadIdx.x & 63) == 0 && hits) atomicAdd(set_calls, (unsigned long long)hits);
+#endif
 }
 
 void launch_voxelize(const TriRec* recs, const uint32_t* unit_base, const uint32_t* block_tri, uint32_t ntri, const GridParams& g, int sat_variant,

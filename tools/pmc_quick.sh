@@ -8,4 +8,4 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS" "SQ_ACTIVE_I
   i=$((i+1))
   timeout -k 10 200 rocprofv3 --pmc $grp --output-format csv -d $R/gpurun_out/pmc_q$i -o pmc -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --big-rays 0 > $R/gpurun_out/pmc_q$i.log 2>&1 || { echo "group $i failed"; tail -5 $R/gpurun_out/pmc_q$i.log; }
 done
-cd $R && python tools/pmc_summary.py gpurun_out/pmc_q* | grep -E "k_trace"
+cd $R && python tools/pmc_summary.py gpurun_out/pmc_q* | grep -E "k_trace|k_voxelize|k_emit_units"
