@@ -660,12 +660,21 @@ __device__ unsigned long long g_trace_util[24];
 // Persistent waves with dynamic work fetch.  Exit condition every wave reaches: the work counter passes the ray count (no
 // refill possible) and every lane's ray (or piece of a ray) has finished; each finishes in a bounded number of steps, and a
 // piece is only split while its t interval is longer than six bricks.
+#ifndef VX_T_STEPS
+#define VX_T_STEPS 4
+#endif
+#ifndef VX_T_ITERS
+#define VX_T_ITERS 2
+#endif
+#ifndef VX_T_REFILL
+#define VX_T_REFILL 44
+#endif
 template <bool LDS_M1>
 __global__ __launch_bounds__(256, 4 /*waves per SIMD: keeps the allocation at <= 128 VGPRs*/) void k_trace(const TraceParams P)
 {
-    constexpr int kStepsPerRound = 4;   // upper-level steps between two brick-test phases
-    constexpr int kItersPerRound = 2;   // (walk, brick test) iterations between two refill checks
-    constexpr int kRefillBelow = 44;    // refill when fewer than this many lanes are busy
+    constexpr int kStepsPerRound = VX_T_STEPS;   // upper-level steps between two brick-test phases
+    constexpr int kItersPerRound = VX_T_ITERS;   // (walk, brick test) iterations between two refill checks
+    constexpr int kRefillBelow = VX_T_REFILL;    // refill when fewer than this many lanes are busy
     constexpr int kChunkRays = 64;      // rays a wave reserves per touch of the global counter
     constexpr int kDonateBelow = 48;    // drain phase: donate work while at most this many lanes are busy
     constexpr float kDonateBricks = 6.0f;  // ... and only from pieces with more than this many bricks of t interval left
