@@ -110,10 +110,13 @@ def main():
     d_aabbs = torch.empty(cap * 6, dtype=torch.float32, device=dev)
     gathered = torch.empty(chunk * world, dtype=torch.int32, device=dev) if world > 1 else None
 
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    # stage boundaries: five events per timed step, all read AFTER the timed region (reading them per step needs a device
+    # synchronize per step, i.e. ~50 us of idle GPU per 1 ms step that is not part of the workload)
+    ev_all = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(a.steps)]
     stage_ms = np.zeros(4)
 
-    def step(timed):
+    def step(timed, k=0):
+        ev = ev_all[k] if timed else None
         if timed:
             ev[0].record()
         if world == 1:
@@ -163,13 +166,13 @@ def main():
     voxhip.profile_enable(True)   # HIP events on the launch stream around the dominant kernel, over the timed region
     t0 = time.perf_counter()
     nocc = 0
-    for _ in range(a.steps):
-        nocc = step(True)
-        torch.cuda.synchronize()
-        for k in range(4):
-            stage_ms[k] += ev[k].elapsed_time(ev[k + 1])
+    for k in range(a.steps):
+        nocc = step(True, k)
     barrier()
     dt = time.perf_counter() - t0
+    for ev in ev_all:
+        for k in range(4):
+            stage_ms[k] += ev[k].elapsed_time(ev[k + 1])
     voxhip.profile_enable(False)
     kern = voxhip.profile_read()   # the dominant kernel only, measured inside the timed region
     voxhip.profile_select(None)
