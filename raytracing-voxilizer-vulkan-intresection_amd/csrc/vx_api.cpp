@@ -139,6 +139,7 @@ vx_status need_device(int dev)
 // small per-handle scratch in device memory
 struct Small {
     unsigned long long bbox_state[8];  // K1's self-cleaning reduction state (initialised once, see ensure_small)
+    vx::DevGrid dgrid;                 // origin + dims as K1 derives them, for kernels queued before the host has seen the bbox
     unsigned long long set_calls;
     unsigned long long nhits;
     unsigned long long trace_counters[4];
@@ -263,22 +264,26 @@ struct Extent {
     uint64_t dim[3];
 };
 
-vx_status compute_extent(const vx_mesh* m, float vs, Small* dsmall, Mail* mail, hipStream_t s, Extent* e)
+vx_status extent_from_bbox(const float* bb, size_t nv, float vs, Extent* e)
 {
-    // one kernel: reduction, result into the host mailbox, state restored, per-build setVoxel counter cleared
-    vx::launch_bbox(m->dv, m->nv, dsmall->bbox_state, mail->bbox, &dsmall->set_calls, s);
-    VX_HIP(hipStreamSynchronize(s));
-    const float* bb = mail->bbox;
     for (int a = 0; a < 3; ++a) {
         e->mn[a] = bb[a];
         e->mx[a] = bb[3 + a];
         e->ctr[a] = (bb[a] + bb[3 + a]) * 0.5f;  // VoxelBuilder.hpp:221
-        if (m->nv == 0) { e->dim[a] = 0; continue; }
+        if (nv == 0) { e->dim[a] = 0; continue; }
         const float q = std::ceil((e->mx[a] - e->mn[a]) / vs);  // :347-349
         if (!(q >= 0.0f) || q > 65535.0f) return fail(VX_ERR_CAPACITY, "grid dimension outside [0, 65535]: voxel size too small for this mesh");
         e->dim[a] = (uint64_t)q;
     }
     return VX_OK;
+}
+
+vx_status compute_extent(const vx_mesh* m, float vs, Small* dsmall, Mail* mail, hipStream_t s, Extent* e)
+{
+    // one kernel: reduction, result into the host mailbox, state restored, per-build setVoxel counter cleared
+    vx::launch_bbox(m->dv, m->nv, dsmall->bbox_state, mail->bbox, &dsmall->set_calls, s);
+    VX_HIP(hipStreamSynchronize(s));
+    return extent_from_bbox(mail->bbox, m->nv, vs, e);
 }
 
 vx_status check_voxel_size(float vs)
@@ -301,20 +306,20 @@ constexpr uint64_t kMaxVoxels = 1ull << 37;  // 16 GiB of bitmask
 // The shared front half of buildVoxelGrid for grids and the octree: records, unit counts, unit bases.  In two parts so that
 // the caller can queue work that does not depend on the unit count (clearing the bitmask) before the host waits for it.
 vx_status setup_launch(const vx_mesh* m, const vx::GridParams& g, int sat, uint64_t tb, uint32_t ntri, uint32_t zlo, uint32_t zhi, DevBuf& recs,
-                       DevBuf& units, DevBuf& ubase, DevBuf& scantmp, Mail* mail, hipStream_t s)
+                       DevBuf& units, DevBuf& ubase, DevBuf& scantmp, Mail* mail, hipStream_t s, const vx::DevGrid* dgrid = nullptr)
 {
     VX_HIP(recs.ensure((size_t)ntri * sizeof(vx::TriRec) + 64));
     VX_HIP(units.ensure(((size_t)ntri + 1) * 4));
     VX_HIP(ubase.ensure(((size_t)ntri + 2) * 4));
     VX_HIP(ensure_scan_tmp(scantmp, vx::scan_tmp_bytes(ntri), s));
-    vx::launch_tri_setup(m->dv, m->di, tb, ntri, g, sat, zlo, zhi, recs.as<vx::TriRec>(), units.as<uint32_t>(), s);
+    vx::launch_tri_setup(m->dv, m->di, tb, ntri, g, sat, zlo, zhi, recs.as<vx::TriRec>(), units.as<uint32_t>(), s, dgrid);
     vx::launch_scan_u32(units.as<uint32_t>(), ubase.as<uint32_t>(), ntri, false, scantmp.p, &mail->units, s, true);
     return VX_OK;
 }
 
-vx_status setup_finish(uint32_t ntri, DevBuf& ubase, DevBuf& btri, Mail* mail, hipStream_t s, uint64_t* total_units)
+vx_status setup_finish(uint32_t ntri, DevBuf& ubase, DevBuf& btri, Mail* mail, hipStream_t s, uint64_t* total_units, bool stream_is_drained = false)
 {
-    VX_HIP(hipStreamSynchronize(s));
+    if (!stream_is_drained) VX_HIP(hipStreamSynchronize(s));
     const unsigned long long tot = mail->units;
     if (tot >= 0xFFFFFFFFull) return fail(VX_ERR_CAPACITY, "more than 2^32 candidate row segments: shard the mesh or the grid");
     *total_units = tot;
@@ -543,46 +548,75 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
     VX_HIP(ensure_small(g->small));
     if (!g->mail) VX_HIP(mail_alloc(&g->mail));
     Small* ds = g->small.as<Small>();
-    Extent ex;
-    VX_TRY(compute_extent(mesh, vs, ds, g->mail, s, &ex));  // also clears the per-build call counter
-    const uint64_t nvox = ex.dim[0] * ex.dim[1] * ex.dim[2];
-    if (nvox > kMaxVoxels) return fail(VX_ERR_CAPACITY, "grid exceeds 2^37 voxels");
-    fill_params(g->g, ex.mn, vs, ex.dim);
-    for (int a = 0; a < 3; ++a) { g->bbmin[a] = ex.mn[a]; g->bbmax[a] = ex.mx[a]; g->bbc[a] = ex.ctr[a]; }
-    VX_TRY(init_grid_storage(g, /*clear=*/false));
-    const size_t mask_bytes = (size_t)(g->g.nwords + 2) * 4;
-
     uint64_t tb = 0, te = mesh->nt;
     if (o.tri_begin || o.tri_end) {
         if (o.tri_begin > o.tri_end || o.tri_end > mesh->nt) return fail(VX_ERR_INVALID_ARG, "triangle shard out of range");
         tb = o.tri_begin;
         te = o.tri_end;
     }
+    const uint32_t ntri = (uint32_t)(te - tb);
+    const bool sharded_words = o.word_begin || o.word_end;
+
+    // Unsharded build: K1 leaves origin + dims in device memory, so the triangle records and the unit scan are queued right
+    // behind it and the host waits ONCE for the bbox and the unit count (every host round trip costs ~20 us of idle GPU: the
+    // wake-up plus the launch latency of an empty queue).  The bitmask of the previous build is cleared in the same window.
+    Extent ex;
+    bool setup_queued = false;
+    size_t cleared = 0;
+    if (!sharded_words && ntri > 0) {
+        vx::GridParams gp{};
+        const float zero3[3] = {0.f, 0.f, 0.f};
+        const uint64_t zdim[3] = {0, 0, 0};
+        fill_params(gp, zero3, vs, zdim);
+        vx::launch_bbox(mesh->dv, mesh->nv, ds->bbox_state, g->mail->bbox, &ds->set_calls, s, vs, &ds->dgrid);
+        VX_TRY(setup_launch(mesh, gp, o.sat_variant, tb, ntri, 0, 0, g->recs, g->units, g->ubase, g->scantmp, g->mail, s, &ds->dgrid));
+        if (g->words.p) {
+            VX_HIP(hipMemsetAsync(g->words.p, 0, g->words.cap, s));
+            cleared = g->words.cap;
+        }
+        VX_HIP(hipStreamSynchronize(s));
+        VX_TRY(extent_from_bbox(g->mail->bbox, mesh->nv, vs, &ex));
+        setup_queued = true;
+    } else {
+        VX_TRY(compute_extent(mesh, vs, ds, g->mail, s, &ex));  // also clears the per-build call counter
+    }
+    const uint64_t nvox = ex.dim[0] * ex.dim[1] * ex.dim[2];
+    if (nvox > kMaxVoxels) return fail(VX_ERR_CAPACITY, "grid exceeds 2^37 voxels");
+    fill_params(g->g, ex.mn, vs, ex.dim);
+    for (int a = 0; a < 3; ++a) { g->bbmin[a] = ex.mn[a]; g->bbmax[a] = ex.mx[a]; g->bbc[a] = ex.ctr[a]; }
+    VX_TRY(init_grid_storage(g, /*clear=*/false));
+    const size_t mask_bytes = (size_t)(g->g.nwords + 2) * 4;
+    if (g->words.fresh) { cleared = 0; g->words.fresh = false; }  // a new block: the early clear hit the old one
+    const bool mask_is_clear = cleared >= mask_bytes;
+
     uint64_t wb = 0, we = g->g.nwords;
-    if (o.word_begin || o.word_end) {
+    if (sharded_words) {
         if (o.word_begin > o.word_end || o.word_end > g->g.nwords) return fail(VX_ERR_INVALID_ARG, "word shard out of range");
         wb = o.word_begin;
         we = o.word_end;
     }
     g->triangles = te - tb;
-    const uint32_t ntri = (uint32_t)(te - tb);
     if (ntri == 0 || nvox == 0 || wb == we) {
-        VX_HIP(hipMemsetAsync(g->words.p, 0, mask_bytes, s));
+        if (!mask_is_clear) VX_HIP(hipMemsetAsync(g->words.p, 0, mask_bytes, s));
         return VX_OK;
     }
 
-    // z slab that contains the voxels of words [wb, we)
-    const uint64_t XY = ex.dim[0] * ex.dim[1];
-    uint32_t zlo = (uint32_t)((wb * 32) / XY);
-    uint64_t zh = (we * 32 + XY - 1) / XY;
-    if (zh > ex.dim[2]) zh = ex.dim[2];
-    const uint32_t zhi = (uint32_t)zh;
-
-    // records + unit scan are queued, THEN the bitmask is cleared (it does not depend on the unit count), then the host waits
-    VX_TRY(setup_launch(mesh, g->g, o.sat_variant, tb, ntri, zlo, zhi, g->recs, g->units, g->ubase, g->scantmp, g->mail, s));
-    VX_HIP(hipMemsetAsync(g->words.p, 0, mask_bytes, s));
     uint64_t U = 0;
-    VX_TRY(setup_finish(ntri, g->ubase, g->btri, g->mail, s, &U));
+    if (setup_queued) {
+        if (!mask_is_clear) VX_HIP(hipMemsetAsync(g->words.p, 0, mask_bytes, s));
+        VX_TRY(setup_finish(ntri, g->ubase, g->btri, g->mail, s, &U, /*stream_is_drained=*/true));
+    } else {
+        // z slab that contains the voxels of words [wb, we)
+        const uint64_t XY = ex.dim[0] * ex.dim[1];
+        uint32_t zlo = (uint32_t)((wb * 32) / XY);
+        uint64_t zh = (we * 32 + XY - 1) / XY;
+        if (zh > ex.dim[2]) zh = ex.dim[2];
+        const uint32_t zhi = (uint32_t)zh;
+        // records + unit scan are queued, THEN the bitmask is cleared (it does not depend on the unit count), then the host waits
+        VX_TRY(setup_launch(mesh, g->g, o.sat_variant, tb, ntri, zlo, zhi, g->recs, g->units, g->ubase, g->scantmp, g->mail, s));
+        VX_HIP(hipMemsetAsync(g->words.p, 0, mask_bytes, s));
+        VX_TRY(setup_finish(ntri, g->ubase, g->btri, g->mail, s, &U));
+    }
     if (U == 0) return VX_OK;
     uint32_t* umask = nullptr;
     if (g->kind == VX_GRID_VEC) {
@@ -609,6 +643,12 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
         VX_TRY(prefix_launch(g, &pending));
     }
     if (g->kind == VX_GRID_VEC) {
+        // The list is emitted into the handle's existing buffer before the host knows the hit count (writes beyond the
+        // buffer's capacity are dropped by the kernel); only a list that outgrew it is emitted again after the wait.
+        const uint64_t cap_rec = g->vec.p ? g->vec.cap / sizeof(vx_aabb) : 0;
+        if (cap_rec)
+            vx::launch_emit_units(g->recs.as<vx::TriRec>(), g->ubase.as<uint32_t>(), g->btri.as<uint32_t>(), ntri, g->g, umask,
+                                  g->hbase.as<uint32_t>(), g->vec.as<vx_aabb>(), nullptr, s, cap_rec);
         VX_HIP(hipStreamSynchronize(s));
         const unsigned long long hits = g->mail->hits;
         if (hits >= 0xFFFFFFFFull) return fail(VX_ERR_CAPACITY, "more than 2^32 voxel hits");
@@ -617,9 +657,11 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
             g->occupied = g->mail->occupied;
             g->occupied_known = true;
         }
-        VX_HIP(g->vec.ensure((size_t)(hits + 1) * sizeof(vx_aabb)));
-        vx::launch_emit_units(g->recs.as<vx::TriRec>(), g->ubase.as<uint32_t>(), g->btri.as<uint32_t>(), ntri, g->g, umask,
-                              g->hbase.as<uint32_t>(), g->vec.as<vx_aabb>(), nullptr, s);
+        if (hits + 1 > cap_rec) {
+            VX_HIP(g->vec.ensure((size_t)(hits + 1) * sizeof(vx_aabb)));
+            vx::launch_emit_units(g->recs.as<vx::TriRec>(), g->ubase.as<uint32_t>(), g->btri.as<uint32_t>(), ntri, g->g, umask,
+                                  g->hbase.as<uint32_t>(), g->vec.as<vx_aabb>(), nullptr, s);
+        }
         g->vec_count = hits;
     }
     VX_HIP(hipGetLastError());

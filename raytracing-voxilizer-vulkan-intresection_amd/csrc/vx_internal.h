@@ -43,12 +43,20 @@ struct ProfScope {
 // K1: bbox of all vertices with the reference's first-occurrence tie rule; out6 = min xyz, max xyz (device).
 // state7: self-cleaning reduction state (initialise ONCE with bbox_state_init); out6 may point to pinned host memory;
 // zero64 (optional) is cleared by the kernel.
+// dgrid (optional, device memory): origin = bbox min and dims = ceil((max - min) / vs) as the host will derive them, for kernels
+// queued behind K1 before the host has read the bbox.
+struct DevGrid {
+    float org[3];
+    uint32_t dim[3];
+    uint32_t pad[2];
+};
 void bbox_state_init(unsigned long long state7[7]);
-void launch_bbox(const float* verts, uint64_t nverts, unsigned long long* state7, float* out6, unsigned long long* zero64, hipStream_t s);
+void launch_bbox(const float* verts, uint64_t nverts, unsigned long long* state7, float* out6, unsigned long long* zero64, hipStream_t s,
+                 float vs = 1.0f, DevGrid* dgrid = nullptr);
 
 // K2a: per-triangle record + number of row-segment work units; zlo/zhi clamp the candidate box to a z slab.
 void launch_tri_setup(const float* verts, const int32_t* idx, uint64_t tri_begin, uint32_t ntri, const GridParams& g,
-                      int sat_variant, uint32_t zlo, uint32_t zhi, TriRec* recs, uint32_t* units, hipStream_t s);
+                      int sat_variant, uint32_t zlo, uint32_t zhi, TriRec* recs, uint32_t* units, hipStream_t s, const DevGrid* dgrid = nullptr);
 
 // exclusive scan of n uint32 (or of their popcounts) into out[0..n] (out[n] = total, saturating check via *total64)
 size_t scan_tmp_bytes(uint64_t n);
@@ -66,7 +74,7 @@ void launch_voxelize(const TriRec* recs, const uint32_t* unit_base, const uint32
 
 // K3: VoxelGridVec / Octree emitters: one output per set bit of unit_mask, in unit order (== reference order).
 void launch_emit_units(const TriRec* recs, const uint32_t* unit_base, const uint32_t* block_tri, uint32_t ntri, const GridParams& g,
-                       const uint32_t* unit_mask, const uint32_t* hit_base, vx_aabb* aabbs, uint64_t* morton, hipStream_t s);
+                       const uint32_t* unit_mask, const uint32_t* hit_base, vx_aabb* aabbs, uint64_t* morton, hipStream_t s, uint64_t cap = ~0ull);
 
 // K4: bitmask -> ordered AABB list (word_prefix = exclusive scan of popcounts, nwords+1 entries)
 void launch_emit_bool_aabbs(const uint32_t* words, const uint32_t* word_prefix, const GridParams& g, vx_aabb* out,

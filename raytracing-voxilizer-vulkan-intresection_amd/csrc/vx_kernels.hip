@@ -80,7 +80,7 @@ __device__ __forceinline__ unsigned ord_bits(float f)
 // host-to-device initialisation nor a second kernel.  `zero64` (optional) is cleared by the same workgroup: the per-build
 // setVoxel call counter.
 __global__ __launch_bounds__(256) void k_bbox(const float* __restrict__ verts, uint64_t nverts, unsigned long long* state, float* out6,
-                                              unsigned long long* zero64)
+                                              unsigned long long* zero64, float vs, DevGrid* dgrid)
 {
     unsigned long long mn[3] = {~0ull, ~0ull, ~0ull}, mx[3] = {0ull, 0ull, 0ull};
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nverts; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -126,20 +126,36 @@ __global__ __launch_bounds__(256) void k_bbox(const float* __restrict__ verts, u
     __syncthreads();
     if (!last_s) return;
     __threadfence();
+    float val = 0.0f;
     if (threadIdx.x < 6) {
         const int a = threadIdx.x;
         const unsigned long long key = __hip_atomic_load(&state[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (nverts == 0) {
-            out6[a] = a < 3 ? INFINITY : -INFINITY;
+            val = a < 3 ? INFINITY : -INFINITY;
         } else {
             const unsigned low = (unsigned)key;
             const unsigned idx = a < 3 ? low : 0xFFFFFFFFu - low;
-            out6[a] = verts[3 * (uint64_t)idx + (a % 3)];
+            val = verts[3 * (uint64_t)idx + (a % 3)];
         }
+        out6[a] = val;
         __hip_atomic_store(&state[a], a < 3 ? ~0ull : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (threadIdx.x == 6) __hip_atomic_store(&state[6], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (threadIdx.x == 7 && zero64) *zero64 = 0ull;
+    if (dgrid && threadIdx.x < 64) {
+        // the grid the host will derive from this bbox (VoxelBuilder.hpp:347-349: origin = bbox min, dim = ceil((max - min) / vs),
+        // same IEEE division), for the kernels that are queued before the host has seen the bbox
+        const float mx = __shfl(val, (int)(threadIdx.x + 3u) & 63, 64);
+        if (threadIdx.x < 3) {
+            uint32_t d = 0;
+            if (nverts) {
+                const float q = ceilf((mx - val) / vs);
+                d = (q >= 0.0f && q <= 65535.0f) ? (uint32_t)q : 0u;  // out of range: the host reports the error, the device sees an empty grid
+            }
+            dgrid->org[threadIdx.x] = val;
+            dgrid->dim[threadIdx.x] = d;
+        }
+    }
 }
 
 void bbox_state_init(unsigned long long state7[7])
@@ -148,9 +164,10 @@ void bbox_state_init(unsigned long long state7[7])
     state7[6] = 0ull;
 }
 
-void launch_bbox(const float* verts, uint64_t nverts, unsigned long long* state7, float* out6, unsigned long long* zero64, hipStream_t s)
+void launch_bbox(const float* verts, uint64_t nverts, unsigned long long* state7, float* out6, unsigned long long* zero64, hipStream_t s, float vs,
+                 DevGrid* dgrid)
 {
-    VX_KL(k_bbox, dim3(nverts ? grid_for(nverts, 256 * 4, 512) : 1u), dim3(256), 0, s, verts, nverts, state7, out6, zero64);
+    VX_KL(k_bbox, dim3(nverts ? grid_for(nverts, 256 * 4, 512) : 1u), dim3(256), 0, s, verts, nverts, state7, out6, zero64, vs, dgrid);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -427,10 +444,16 @@ __device__ __forceinline__ void trim_axis(float a0, float a1, float a2, float or
 
 __global__ __launch_bounds__(256) void k_tri_setup(const float* __restrict__ verts, const int32_t* __restrict__ idx, uint64_t tri_begin,
                                                    uint32_t ntri, GridParams g, float vsize, uint32_t zlo, uint32_t zhi,
-                                                   TriRec* __restrict__ recs, uint32_t* __restrict__ units)
+                                                   TriRec* __restrict__ recs, uint32_t* __restrict__ units, const DevGrid* __restrict__ dgrid)
 {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= ntri) return;
+    if (dgrid) {  // origin and dims from the bbox kernel queued in front (the host has not seen them yet); whole grid in z
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { g.org[a] = dgrid->org[a]; g.dim[a] = dgrid->dim[a]; }
+        zlo = 0u;
+        zhi = g.dim[2];
+    }
     const int32_t* ip = idx + 3 * (tri_begin + t);
     TriRec r;
 #pragma unroll
@@ -466,12 +489,12 @@ __global__ __launch_bounds__(256) void k_tri_setup(const float* __restrict__ ver
 }
 
 void launch_tri_setup(const float* verts, const int32_t* idx, uint64_t tri_begin, uint32_t ntri, const GridParams& g, int sat_variant,
-                      uint32_t zlo, uint32_t zhi, TriRec* recs, uint32_t* units, hipStream_t s)
+                      uint32_t zlo, uint32_t zhi, TriRec* recs, uint32_t* units, hipStream_t s, const DevGrid* dgrid)
 {
     if (!ntri) return;
     // serial driver: voxelSize = halfVoxelSize.x * 2.0f (VoxelBuilder.hpp:173); threaded driver: vSize = voxelSize (:500)
     const float vsize = sat_variant == 0 ? g.half * 2.0f : g.vs;
-    VX_KL(k_tri_setup, dim3((ntri + 255) / 256), dim3(256), 0, s, verts, idx, tri_begin, ntri, g, vsize, zlo, zhi, recs, units);
+    VX_KL(k_tri_setup, dim3((ntri + 255) / 256), dim3(256), 0, s, verts, idx, tri_begin, ntri, g, vsize, zlo, zhi, recs, units, dgrid);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -674,7 +697,7 @@ void launch_voxelize(const TriRec* recs, const uint32_t* unit_base, const uint32
 __global__ __launch_bounds__(256) void k_emit_units(const TriRec* __restrict__ recs, const uint32_t* __restrict__ unit_base,
                                                     const uint32_t* __restrict__ block_tri, uint32_t ntri, GridParams g,
                                                     const uint32_t* __restrict__ unit_mask, const uint32_t* __restrict__ hit_base,
-                                                    vx_aabb* __restrict__ aabbs, uint64_t* __restrict__ morton)
+                                                    vx_aabb* __restrict__ aabbs, uint64_t* __restrict__ morton, uint64_t cap /*records the output can hold*/)
 {
     __shared__ UnitStage stage;
     for_each_unit(recs, unit_base, block_tri, ntri, stage, [&](uint32_t u, uint32_t t, const TriRec& r, uint32_t rel) {
@@ -686,6 +709,7 @@ __global__ __launch_bounds__(256) void k_emit_units(const TriRec* __restrict__ r
             const uint32_t b = __ffs(mask) - 1;
             mask &= mask - 1;
             const uint32_t x = w.xseg + b;
+            if (off >= cap) return;  // speculative emission into an existing buffer: the host re-emits after growing it
             if (aabbs) {
                 float bb[6];
                 cell_aabb(g, x, w.y, w.z, bb);
@@ -701,10 +725,10 @@ __global__ __launch_bounds__(256) void k_emit_units(const TriRec* __restrict__ r
 }
 
 void launch_emit_units(const TriRec* recs, const uint32_t* unit_base, const uint32_t* block_tri, uint32_t ntri, const GridParams& g,
-                       const uint32_t* unit_mask, const uint32_t* hit_base, vx_aabb* aabbs, uint64_t* morton, hipStream_t s)
+                       const uint32_t* unit_mask, const uint32_t* hit_base, vx_aabb* aabbs, uint64_t* morton, hipStream_t s, uint64_t cap)
 {
     if (!ntri) return;
-    VX_KL(k_emit_units, dim3(kMaxBlocks), dim3(256), 0, s, recs, unit_base, block_tri, ntri, g, unit_mask, hit_base, aabbs, morton);
+    VX_KL(k_emit_units, dim3(kMaxBlocks), dim3(256), 0, s, recs, unit_base, block_tri, ntri, g, unit_mask, hit_base, aabbs, morton, cap);
 }
 
 // ------------------------------------------------------------------------------------------------------------
