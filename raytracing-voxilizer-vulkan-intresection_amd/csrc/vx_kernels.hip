@@ -158,6 +158,9 @@ __global__ __launch_bounds__(256) void k_bbox(const float* __restrict__ verts, u
     }
 }
 
+#ifndef VX_BBOX_PER_THREAD
+#define VX_BBOX_PER_THREAD 4
+#endif
 void bbox_state_init(unsigned long long state7[7])
 {
     for (int a = 0; a < 3; ++a) { state7[a] = ~0ull; state7[3 + a] = 0ull; }
@@ -167,7 +170,7 @@ void bbox_state_init(unsigned long long state7[7])
 void launch_bbox(const float* verts, uint64_t nverts, unsigned long long* state7, float* out6, unsigned long long* zero64, hipStream_t s, float vs,
                  DevGrid* dgrid)
 {
-    VX_KL(k_bbox, dim3(nverts ? grid_for(nverts, 256 * 4, 512) : 1u), dim3(256), 0, s, verts, nverts, state7, out6, zero64, vs, dgrid);
+    VX_KL(k_bbox, dim3(nverts ? grid_for(nverts, 256 * VX_BBOX_PER_THREAD, 512) : 1u), dim3(256), 0, s, verts, nverts, state7, out6, zero64, vs, dgrid);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -283,7 +286,13 @@ constexpr unsigned long long kScanFlagA = 1ull << 62, kScanFlagP = 2ull << 62, k
 
 // Large tiles (1024 threads x 16 elements): a 4M-element scan is 256 tiles, so the look-back chain is a handful of hops
 // (with 2048-element tiles the chain of 2048 hops at cross-XCD atomic latency cost as much as the three-pass scan).
-constexpr int kOneBlock = 1024, kOneItems = 16, kOneTile = kOneBlock * kOneItems;
+#ifndef VX_SCAN_BLOCK
+#define VX_SCAN_BLOCK 1024
+#endif
+#ifndef VX_SCAN_ITEMS
+#define VX_SCAN_ITEMS 16
+#endif
+constexpr int kOneBlock = VX_SCAN_BLOCK, kOneItems = VX_SCAN_ITEMS, kOneTile = kOneBlock * kOneItems;
 
 template <bool POPC>
 __global__ __launch_bounds__(kOneBlock) void k_scan_onepass(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t n,
