@@ -48,47 +48,70 @@ namespace vx {
     } while (0)
 
 // ------------------------------------------------------------------------------------------------------------
-// Brick-major re-tiling of the occupancy bitmask.  One thread per (brick, z slice): gathers 8 rows of 8 bits.
+// Brick-major re-tiling of the occupancy bitmask through LDS.  A workgroup takes 64 bricks in a row along x for one (by, bz):
+// 64 voxel rows (8 z x 8 y) of 512 voxels.  Reads: row-contiguous words (a wave reads 64 consecutive bytes x 4 rows per
+// instruction instead of 64 bytes in total), funnel-shifted to the chunk's own 32-voxel alignment.  Writes: thread t holds
+// slice t%8 of brick t/8, i.e. consecutive threads write consecutive 8-byte words -- 4 KiB contiguous per workgroup.
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_build_bricks(const uint32_t* __restrict__ words, uint32_t X, uint32_t Y, uint32_t Z, uint32_t BX, uint32_t BY,
-                                                      uint32_t BZ, unsigned long long* __restrict__ bricks)
+                                                      uint32_t BZ, uint32_t chunks_x, uint64_t nwords, unsigned long long* __restrict__ bricks)
 {
-    const uint64_t n = (uint64_t)BX * BY * BZ * 8ull;
-    for (uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x; t < n; t += (uint64_t)gridDim.x * 256u) {
-        // consecutive threads: consecutive bricks along x for a fixed slice, so their byte reads fall in the same rows
-        const uint32_t bx = (uint32_t)(t % BX);
-        const uint64_t q = t / BX;
-        const uint32_t s = (uint32_t)(q & 7u);
-        const uint64_t q2 = q >> 3;
-        const uint32_t by = (uint32_t)(q2 % BY), bz = (uint32_t)(q2 / BY);
-        const uint32_t z = bz * 8u + s, x0 = bx * 8u;
-        unsigned long long bits = 0;
-        if (z < Z) {
-            const uint32_t nb = (X - x0) < 8u ? (X - x0) : 8u;
-            for (uint32_t yy = 0; yy < 8u; ++yy) {
-                const uint32_t y = by * 8u + yy;
-                if (y >= Y) break;
-                const uint64_t i0 = (uint64_t)X * ((uint64_t)y + (uint64_t)Y * z) + x0;
+    __shared__ uint32_t rows[64][17];  // [z*8 + y][32-voxel chunk of the 512]; padded against bank conflicts of the column reads
+    const uint64_t ngroups = (uint64_t)chunks_x * BY * BZ;
+    for (uint64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const uint32_t cx = (uint32_t)(grp % chunks_x);
+        const uint64_t q = grp / chunks_x;
+        const uint32_t by = (uint32_t)(q % BY), bz = (uint32_t)(q / BY);
+        const uint32_t x0 = cx * 512u;
+        // ---- load: 64 rows x 16 words, four items per thread
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t item = (uint32_t)k * 256u + threadIdx.x;
+            const uint32_t r = item >> 4, j = item & 15u;
+            const uint32_t z = bz * 8u + (r >> 3), y = by * 8u + (r & 7u), xs = x0 + j * 32u;
+            uint32_t val = 0u;
+            if (z < Z && y < Y && xs < X) {
+                const uint64_t i0 = (uint64_t)X * ((uint64_t)y + (uint64_t)Y * z) + xs;
                 const uint32_t sh = (uint32_t)i0 & 31u;
                 const uint64_t wi = i0 >> 5;
-                uint32_t val = words[wi] >> sh;
-                if (sh + nb > 32u) val |= words[wi + 1] << (32u - sh);
-                val &= (1u << nb) - 1u;
-                bits |= (unsigned long long)val << (yy * 8u);
+                val = words[wi] >> sh;
+                if (sh && wi + 1 < nwords) val |= words[wi + 1] << (32u - sh);
+                const uint32_t nb = X - xs;  // voxels of this row left from xs on
+                if (nb < 32u) val &= (1u << nb) - 1u;
+            }
+            rows[r][j] = val;
+        }
+        __syncthreads();
+        // ---- store: two (brick, slice) pairs per thread
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const uint32_t item = (uint32_t)k * 256u + threadIdx.x;
+            const uint32_t b = item >> 3, sl = item & 7u;
+            const uint32_t bx = cx * 64u + b;
+            if (bx < BX) {
+                unsigned long long bits = 0ull;
+                const uint32_t sh = (b & 3u) * 8u;
+#pragma unroll
+                for (uint32_t yy = 0; yy < 8u; ++yy) bits |= (unsigned long long)((rows[sl * 8u + yy][b >> 2] >> sh) & 0xFFu) << (yy * 8u);
+                const uint64_t brick = (uint64_t)bx + (uint64_t)BX * ((uint64_t)by + (uint64_t)BY * bz);
+                bricks[brick * 8ull + sl] = bits;
             }
         }
-        const uint64_t brick = (uint64_t)bx + (uint64_t)BX * ((uint64_t)by + (uint64_t)BY * bz);
-        bricks[brick * 8ull + s] = bits;
+        __syncthreads();
     }
 }
 
 void launch_build_bricks(const uint32_t* words, const uint32_t dim[3], const uint32_t bdim[3], unsigned long long* bricks, hipStream_t s)
 {
-    const uint64_t n = (uint64_t)bdim[0] * bdim[1] * bdim[2] * 8ull;
+    const uint64_t n = (uint64_t)bdim[0] * bdim[1] * bdim[2];
     if (!n) return;
-    uint64_t nblk = (n + 255) / 256;
-    if (nblk > 8192) nblk = 8192;
-    VX_KL(k_build_bricks, dim3((unsigned)nblk), dim3(256), 0, s, words, dim[0], dim[1], dim[2], bdim[0], bdim[1], bdim[2], bricks);
+    const uint32_t chunks_x = (bdim[0] + 63u) / 64u;
+    const uint64_t ngroups = (uint64_t)chunks_x * bdim[1] * bdim[2];
+    const uint64_t nvox = (uint64_t)dim[0] * dim[1] * dim[2];
+    const uint64_t nwords = (nvox + 31) / 32;
+    uint64_t nblk = ngroups;
+    if (nblk > 16384) nblk = 16384;
+    VX_KL(k_build_bricks, dim3((unsigned)nblk), dim3(256), 0, s, words, dim[0], dim[1], dim[2], bdim[0], bdim[1], bdim[2], chunks_x, nwords, bricks);
 }
 
 // Per brick: the bounding box of its occupied cells, 3 bits per bound (xmin | xmax<<3 | ymin<<6 | ymax<<9 | zmin<<12 |
