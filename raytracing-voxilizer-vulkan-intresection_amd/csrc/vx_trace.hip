@@ -483,7 +483,7 @@ __device__ __forceinline__ void brick_test(Lane& R, const GridParams& g, const T
 // test for all lanes of the wave together (phase separation keeps the wave's lanes in the same code).
 // Returns false when the ray is finished.
 template <bool LDS_M1>
-__device__ __forceinline__ bool upper_step(Lane& R, const GridParams& g, const TraceMips& M, const uint32_t* __restrict__ m1_lds, float inv_vs)
+__device__ __forceinline__ bool upper_step(Lane& R, const GridParams& g, const TraceMips& M, const uint32_t* __restrict__ m1_lds, uint32_t m2_off, float inv_vs)
 {
     const int lvl = R.lvl;
     const bool ex = (R.tMx <= R.tMy) && (R.tMx <= R.tMz);
@@ -534,7 +534,8 @@ __device__ __forceinline__ bool upper_step(Lane& R, const GridParams& g, const T
         } else {
             if ((unsigned)nx < M.d2[0] && (unsigned)ny < M.d2[1] && (unsigned)nz < M.d2[2]) {
                 const uint32_t i = (uint32_t)nx + M.d2[0] * ((uint32_t)ny + M.d2[1] * (uint32_t)nz);
-                R.occ |= ((M.w2[i >> 5] >> (i & 31u)) & 1u) != 0u;
+                const uint32_t w = LDS_M1 ? m1_lds[m2_off + (i >> 5)] : M.w2[i >> 5];  // with the L1 mip in LDS the (tiny) L2 mip sits behind it
+                R.occ |= ((w >> (i & 31u)) & 1u) != 0u;
             }
         }
         if (R.todo) return true;  // more cells to look at; otherwise finish the cell right away
@@ -638,7 +639,7 @@ struct TraceHot {
     float tmin;
     int any_hit;
     uint32_t m1_words;
-    uint32_t pad;
+    uint32_t m2_words;
 };
 struct TraceCold {
     const float* rays;            // null: primary rays from *cam
@@ -707,6 +708,7 @@ __global__ __launch_bounds__(256, 4 /*waves per SIMD: keeps the allocation at <=
     extern __shared__ __attribute__((aligned(16))) uint32_t m1_lds[];
     if (LDS_M1) {
         for (uint32_t i = threadIdx.x; i < P.hot.m1_words; i += 256u) m1_lds[i] = M.w1[i];
+        for (uint32_t i = threadIdx.x; i < P.hot.m2_words; i += 256u) m1_lds[P.hot.m1_words + i] = M.w2[i];
         __syncthreads();
     }
     const int lane = threadIdx.x & 63;
@@ -862,7 +864,7 @@ __global__ __launch_bounds__(256, 4 /*waves per SIMD: keeps the allocation at <=
                 VX_UTIL_ADD(5, 1)
                 VX_UTIL_ADD(6, __popcll(gm))
                 if (go) {
-                    if (!upper_step<LDS_M1>(R, g, M, m1_lds, inv_vs)) finished = true;
+                    if (!upper_step<LDS_M1>(R, g, M, m1_lds, P.hot.m1_words, inv_vs)) finished = true;
 #ifdef VX_TRACE_DEBUG_STEPS
                     ++dbg_steps;
 #endif
@@ -1049,7 +1051,9 @@ void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* wo
     const dim3 grid((unsigned)nblk), block(256);
     const bool want_rank = (io.prim_out || io.hits || io.normal_out) && word_prefix && idx_tmp && io.t_out;
     unsigned long long* idx_out = want_rank ? idx_tmp : nullptr;
-    const size_t shmem = lds_m1 ? (size_t)m1_words * 4 : 0;
+    const uint64_t n2 = (uint64_t)mips.d2[0] * mips.d2[1] * mips.d2[2];
+    const uint32_t m2_words = (uint32_t)((n2 + 31) / 32);
+    const size_t shmem = lds_m1 ? (size_t)(m1_words + m2_words) * 4 : 0;
     // intra-wave work donation in the drain phase (default on; VOXHIP_TRACE_DONATE=0 disables).  The merge key holds the
     // voxel index in 32 bits and the list holds ray numbers in 32 bits.
     static const int env_donate = getenv("VOXHIP_TRACE_DONATE") ? atoi(getenv("VOXHIP_TRACE_DONATE")) : 1;
@@ -1063,6 +1067,7 @@ void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* wo
     P.hot.tmin = io.tmin;
     P.hot.any_hit = io.any_hit ? 1 : 0;
     P.hot.m1_words = m1_words;
+    P.hot.m2_words = m2_words;
     P.cold.rays = io.rays;
     P.cold.cam = io.cam_dev;  // device copy of the camera (null for explicit rays)
     P.cold.tmax_per_ray = io.tmax_per_ray;
