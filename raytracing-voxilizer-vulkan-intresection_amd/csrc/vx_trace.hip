@@ -728,6 +728,7 @@ __global__ __launch_bounds__(256, 4 /*waves per SIMD: keeps the allocation at <=
     int bt_tot[4] = {0, 0, 0, 0};
     int bt_work = 0;
     unsigned long long dbg_last = __builtin_readcyclecounter();
+    unsigned long long dbg_drain_at = ~0ull;
 #endif
 #ifdef VX_TRACE_DEBUG_CYCLES
     unsigned long long dbg_t0 = 0;
@@ -756,7 +757,12 @@ __global__ __launch_bounds__(256, 4 /*waves per SIMD: keeps the allocation at <=
                 if (chunk_cur > chunk_end) chunk_cur = chunk_end;
                 if (base + (uint64_t)kChunkRays >= nrays) drained_global = true;
             }
-            if (drained_global && chunk_cur >= chunk_end) drained = true;
+            if (drained_global && chunk_cur >= chunk_end) {
+                drained = true;
+#ifdef VX_TRACE_DEBUG_UTIL
+                if (dbg_drain_at == ~0ull) { dbg_drain_at = 0; for (int i = 0; i < 5; ++i) dbg_drain_at += dbg_c[i]; }
+#endif
+            }
             if (!busy) {
                 const uint64_t pos = (uint64_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
                 const uint64_t mine = pos < take ? first + pos : (take < need ? second + (pos - take) : nrays);
@@ -938,8 +944,13 @@ __global__ __launch_bounds__(256, 4 /*waves per SIMD: keeps the allocation at <=
         for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
         if (lane == 0) atomicAdd(&g_trace_util[16 + i], (unsigned long long)v);
     }
-    if (lane == 0)
-        for (int i = 0; i < 13; ++i) atomicAdd(&g_trace_util[i], dbg_c[i]);
+    if (lane == 0) {
+        unsigned long long life = 0;
+        for (int i = 0; i < 13; ++i) { atomicAdd(&g_trace_util[i], dbg_c[i]); if (i < 5) life += dbg_c[i]; }
+        atomicMax(&g_trace_util[20], life);                                  // longest wave
+        atomicAdd(&g_trace_util[21], life > dbg_drain_at ? life - dbg_drain_at : 0ull);  // cycles after the wave's queue ran dry
+        atomicAdd(&g_trace_util[22], 1ull);                                  // waves
+    }
 #endif
 }
 

@@ -30,3 +30,4 @@ print("rounds          %d, mean busy lanes %.1f" % (o[9], o[10] / max(o[9], 1)))
 print("cycles per walk iteration %.0f, per brick phase %.0f" % (o[2] / max(o[5], 1), o[3] / max(o[7], 1)))
 print("brick tests: %d past culling of %d; per test past culling: %.2f slices, %.2f rows, %.2f slab tests" % (o[19], o[8], o[16] / max(o[19], 1), o[17] / max(o[19], 1), o[18] / max(o[19], 1)))
 print("brick phase divergence: slowest lane's work / mean work of the lanes with a brick = %.2f" % (o[11] / max(o[12] / max(o[8] / max(o[7], 1), 1), 1)))
+print("waves %d: mean lifetime %.3g cycles, longest %.3g (x%.2f); mean time after the wave's queue ran dry %.3g cycles (%.0f %% of its life)" % (o[22], tot / max(o[22], 1), o[20], o[20] / max(tot / max(o[22], 1), 1), o[21] / max(o[22], 1), 100.0 * o[21] / max(tot, 1)))
