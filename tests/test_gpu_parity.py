@@ -449,6 +449,35 @@ def test_random_soups_property(gpu):
             assert np.array_equal(tt, ot) and np.array_equal(pp, op), "case %d rays" % case
 
 
+def test_far_from_origin(gpu):
+    """Meshes far from the origin (coordinates 1e2..2e3 x their own size): float32 spacing is then a visible fraction of a voxel.
+    The voxelizer must still match bit for bit (same roundings as the reference), and the ray kernel's tolerance, which scales
+    with max |coordinate|, must still enclose every box the brute-force formula can report."""
+    rng = np.random.default_rng(77)
+    for case in range(10):
+        n = int(rng.integers(20, 300))
+        scale = float(10.0 ** rng.uniform(-1, 1))
+        off = rng.choice([-1.0, 1.0], 3) * rng.uniform(100.0, 2000.0, 3) * scale
+        v = (rng.uniform(0, 1, (3 * n, 3)) * scale + off).astype(np.float32)
+        t = np.arange(3 * n, dtype=np.int32).reshape(-1, 3)
+        ext = float((v.max(0) - v.min(0)).max())
+        vs = np.float32(ext / float(rng.integers(4, 40)))
+        mesh = gpu.Mesh.from_arrays(v, t)
+        g = gpu.Grid.voxelize(mesh, vs, gpu.GRID_VEC, sat_variant=case % 2)
+        ow, calls, gi = oracle.build_bool(v, t, vs, threads=0, sat=case % 2)
+        assert g.describe()["dim"] == gi["dim"], (case, g.describe()["dim"], gi["dim"])
+        assert np.array_equal(g.bitmask(), ow), "case %d bitmask" % case
+        assert g.aabbs().tobytes() == oracle.build_vec(v, t, vs, threads=0, sat=case % 2).tobytes(), "case %d vec" % case
+        oa = oracle.bool_aabbs(ow, gi, vs)
+        if len(oa):
+            hi = gi["bmin"] + np.array(gi["dim"], np.float32) * vs
+            rays = vx_scenes.random_rays(2000, gi["bmin"], hi, seed=100 + case)
+            tt, pp, _ = g.trace(rays)
+            ot, op = oracle.trace_brute(oa, rays)
+            assert np.array_equal(tt > 0, ot > 0), "case %d hit/miss" % case
+            assert np.array_equal(tt, ot) and np.array_equal(pp, op), "case %d rays" % case
+
+
 def test_soup_200k_at_512(gpu):
     """Mid-size soup at full 512^3 resolution against the (threaded) oracle: bitmask + octree items + node array."""
     v, t = vx_scenes.soup(200_000, seed=9, edge=0.006)
