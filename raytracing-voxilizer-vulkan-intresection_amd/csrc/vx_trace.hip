@@ -436,6 +436,9 @@ __device__ __forceinline__ void brick_test(Lane& R, const GridParams& g, const T
             int r0 = (int)floorf((fminf(ya, yb) - tol2 - loy) * inv_vs), r1 = (int)floorf((fmaxf(ya, yb) + tol2 - loy) * inv_vs);
             r0 = r0 < oymin ? oymin : r0;
             r1 = r1 > oymax ? oymax : r1;
+            // Candidates of the whole slice first, exact tests afterwards: nested divergent loops cost a wave the PRODUCT of its
+            // lanes' longest trip counts (rows x candidates per row); two loops in sequence cost their sum.
+            unsigned long long cand = 0ull;
             for (int r = r0; r <= r1; ++r) {
                 const uint32_t rowbits = (uint32_t)(bits >> (8 * r)) & 0xFFu;
                 if (!rowbits) continue;
@@ -454,21 +457,21 @@ __device__ __forceinline__ void brick_test(Lane& R, const GridParams& g, const T
                 c0 = c0 < 0 ? 0 : c0;
                 c1 = c1 > 7 ? 7 : c1;
                 if (c0 > c1) continue;
-                uint32_t cand = rowbits & ((2u << c1) - (1u << c0));
-                while (cand) {
-                    const int b = __ffs(cand) - 1;
-                    cand &= cand - 1;
-                    VX_BT_COUNT(2)
-                    const uint32_t x = (uint32_t)(fx + b), y = (uint32_t)(fy + r), z = (uint32_t)(fz + s);
-                    float bb[6];
-                    cell_aabb(g, x, y, z, bb);
-                    const float t = hit_aabb(bb, o3, inv3);                       // rint:46-56
-                    const uint64_t i = (uint64_t)x + (uint64_t)g.dim[0] * ((uint64_t)y + (uint64_t)g.dim[1] * (uint64_t)z);
-                    if (t > 0.0f && t >= tmin && t <= tmax &&                     // rint:69, rgen:50-51
-                        (t < R.best || (t == R.best && i < R.best_idx))) {
-                        R.best = t;
-                        R.best_idx = i;
-                    }
+                cand |= (unsigned long long)(rowbits & ((2u << c1) - (1u << c0))) << (8 * r);
+            }
+            while (cand) {
+                const int b = __ffsll((long long)cand) - 1;
+                cand &= cand - 1ull;
+                VX_BT_COUNT(2)
+                const uint32_t x = (uint32_t)(fx + (b & 7)), y = (uint32_t)(fy + (b >> 3)), z = (uint32_t)(fz + s);
+                float bb[6];
+                cell_aabb(g, x, y, z, bb);
+                const float t = hit_aabb(bb, o3, inv3);                       // rint:46-56
+                const uint64_t i = (uint64_t)x + (uint64_t)g.dim[0] * ((uint64_t)y + (uint64_t)g.dim[1] * (uint64_t)z);
+                if (t > 0.0f && t >= tmin && t <= tmax &&                     // rint:69, rgen:50-51
+                    (t < R.best || (t == R.best && i < R.best_idx))) {
+                    R.best = t;
+                    R.best_idx = i;
                 }
             }
         }
