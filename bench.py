@@ -12,6 +12,10 @@ N>1 (one process per GPU, torch.distributed / RCCL): every rank voxelizes only i
 one all-gather of the shards over xGMI rebuilds the full bitmask on every rank (word-disjoint shards: all-gather == OR),
 then every rank traces its own R rays (weak scaling in rays).  value = all ranks' rays / max-over-ranks step time.
 
+Timing: W untimed warm-up steps, an untimed survey pass (HIP events around EVERY kernel launch -> `kernels_survey_pass`, the
+dominant kernel), then EXACTLY K timed steps between barrier + synchronize on both sides; inside the timed region only the
+dominant kernel is bracketed by events (-> `roofline`), and the stage events are read after the region.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
