@@ -237,9 +237,15 @@ def main():
                 traffic = tj["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
         except (OSError, ValueError):
             pass
+        issue = None
+        try:  # instruction-issue view from the SQ_* PMC passes (profiles/, committed): the kernel is not HBM bound
+            with open(os.path.join(ROOT, "profiles", "r1_issue.json")) as fh:
+                issue = json.load(fh)["kernels"].get(dom)
+        except (OSError, ValueError, KeyError):
+            pass
         roof = {"bound": "hbm", "kernel": dom, "avg_launch_ms": round(avg_ms, 5), "launches": int(n),
                 "algorithmic_bytes": ab, "achieved": round(ach, 2) if ach else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 5) if ach else None, "traffic": traffic,
+                "frac": round(ach / HBM_PEAK_GBS, 5) if ach else None, "traffic": traffic, "issue": issue,
                 "note": "VALU/latency-bound kernel: algorithmic HBM bytes are tiny next to its arithmetic; traffic from rocprofv3 PMC passes is in profiles/"}
     # per-kernel table: the untimed survey pass (every launch bracketed by events)
     kernels = {k: {"avg_ms": round(v[0] / max(v[1], 1), 5), "launches_per_step": round(v[1] / survey_steps, 2)} for k, v in sorted(kern_all.items())}

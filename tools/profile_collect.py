@@ -58,6 +58,20 @@ for base, e in traffic["kernels"].items():
     e["hbm_bytes_per_launch"] = e["fetch_bytes_raw"] + e["write_bytes"]
     e["hbm_bytes_if_fetch_x2"] = 2 * e["fetch_bytes_raw"] + e["write_bytes"]
 json.dump(traffic, open(os.path.join(out, tag + "_traffic.json"), "w"), indent=1)
+# instruction-issue view of the same passes (the ray and SAT kernels are issue/latency bound, not HBM bound)
+issue = {"note": "per launch, from the SQ_* passes: VALU wave-instructions, lane utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU), "
+                 "share of wave cycles spent waiting = SQ_WAIT_ANY / SQ_WAVE_CYCLES", "kernels": {}}
+for k, v in allc.items():
+    if k.startswith("vx::") and "SQ_INSTS_VALU" in v and "SQ_ACTIVE_INST_VALU" in v and v["SQ_ACTIVE_INST_VALU"] > 0:
+        base = k[4:].split("<")[0]
+        if base in issue["kernels"]:
+            continue
+        e = {"valu_wave_insts": v["SQ_INSTS_VALU"], "salu_insts": v.get("SQ_INSTS_SALU"),
+             "lane_utilisation": round(v["SQ_THREAD_CYCLES_VALU"] / (64.0 * v["SQ_ACTIVE_INST_VALU"]), 4)}
+        if v.get("SQ_WAVE_CYCLES"):
+            e["wait_share_of_wave_cycles"] = round(v.get("SQ_WAIT_ANY", 0.0) / v["SQ_WAVE_CYCLES"], 4)
+        issue["kernels"][base] = e
+json.dump(issue, open(os.path.join(out, tag + "_issue.json"), "w"), indent=1)
 b = os.path.join(src, "bench_under_kernel_trace.json")
 if os.path.exists(b) and os.path.getsize(b):
     shutil.copy(b, os.path.join(out, tag + "_bench_under_kernel_trace.json"))
