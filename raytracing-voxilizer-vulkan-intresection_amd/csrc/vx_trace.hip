@@ -875,7 +875,15 @@ __global__ __launch_bounds__(256, 4 /*waves per SIMD: keeps the allocation at <=
                 if (go) {
                     if (!upper_step<LDS_M1>(R, g, M, m1_lds, P.hot.m1_words, inv_vs)) finished = true;
 #ifdef VX_TRACE_DEBUG_STEPS
+#if VX_TRACE_DEBUG_STEPS == 3
+                    {   // count only steps whose cell lies outside the grid (halo block / halo bricks)
+                        const bool outside = R.lvl == 2 ? ((unsigned)R.cx >= M.d2[0] || (unsigned)R.cy >= M.d2[1] || (unsigned)R.cz >= M.d2[2])
+                                                        : ((unsigned)R.cx >= M.d1[0] || (unsigned)R.cy >= M.d1[1] || (unsigned)R.cz >= M.d1[2]);
+                        if (outside) ++dbg_steps;
+                    }
+#elif VX_TRACE_DEBUG_STEPS != 2
                     ++dbg_steps;
+#endif
 #endif
                 }
             }
@@ -894,6 +902,9 @@ __global__ __launch_bounds__(256, 4 /*waves per SIMD: keeps the allocation at <=
                 bt_work = bt_cnt[0] * 20 + bt_cnt[1] * 40 + bt_cnt[2] * 60;
 #else
                 brick_test(R, g, M, inv_vs, R.tolp, R.bx, R.by, R.bz, P.hot.tmin, R.tmax);
+#endif
+#if defined(VX_TRACE_DEBUG_STEPS) && VX_TRACE_DEBUG_STEPS == 2
+                ++dbg_steps;  // diagnostic: brick tests per ray
 #endif
                 R.pending = false;
                 // shadow query (gl_RayFlagsTerminateOnFirstHitEXT, raytrace2.rchit:108): any accepted hit ends the ray
