@@ -909,6 +909,10 @@ static vx_status trace_common(vx_grid* g, vx::TraceIO io)
         io.cam_dev = g->camera.as<vx::Camera>();
     }
     VX_HIP(g->spill.ensure(vx::trace_spill_bytes(io.nrays)));
+    if (g->spill.fresh) {  // split flags: all zero between launches (the merge step clears what the trace sets)
+        VX_HIP(hipMemsetAsync(g->spill.p, 0, g->spill.cap, g->stream));
+        g->spill.fresh = false;
+    }
     VX_HIP(g->keys.ensure((size_t)io.nrays * 8 + 8));
     vx::launch_trace(g->g, mips, prefix, io, g->small.as<Small>()->trace_counters, idx_tmp, g->spill.p, g->keys.as<unsigned long long>(), g->stream);
     VX_HIP(hipGetLastError());

@@ -655,9 +655,8 @@ struct TraceCold {
     unsigned long long* idx_out;
     uint8_t* shadowed_out;
     unsigned long long* next_item;   // work counter
-    unsigned long long* nsplit;      // number of rays in split_list
     unsigned long long* keys;        // per ray: atomicMin merge key of the pieces of a split ray
-    uint32_t* split_list;            // null: no work donation
+    uint8_t* split_flag;             // per ray: 1 once the ray has been split (null: no work donation); all zero between launches
 };
 struct TraceParams {
     TraceHot hot;
@@ -809,11 +808,11 @@ __global__ __launch_bounds__(256, 4 /*waves per SIMD: keeps the allocation at <=
         // its t interval left hands the FAR half to an idle lane of its wave (ray and interval travel by shuffles); the two
         // pieces are walked independently (every cell overlapping the piece, with the usual probes) and meet in a 64-bit
         // atomicMin of (t bits << 32 | voxel index) -- the same "closest, then lower index" order a single walk uses.
-        // k_merge_list then writes the outputs of the rays that were split.
+        // The outputs of the rays that were split are written from their keys afterwards (k_rank, or k_merge_flags).
         if (drained && __popcll(bm) <= kDonateBelow) {
             const ColdPtr C = cold_params();
-            uint32_t* split_list = C->split_list;
-            if (split_list) {
+            uint8_t* split_flag = C->split_flag;
+            if (split_flag) {
                 const int nb = __popcll(bm);
                 const float t_cur = fmaxf(R.t_in, R.tn), t_end = fminf(R.tf, R.best + R.tau_term);
                 const float brick_time = 8.0f * g.vs / fmaxf(fmaxf(fabsf(R.dx), fabsf(R.dy)), fabsf(R.dz));
@@ -826,15 +825,8 @@ __global__ __launch_bounds__(256, 4 /*waves per SIMD: keeps the allocation at <=
                     const int drank = __popcll(dm & ((1ull << lane) - 1ull));
                     const bool donor = can && drank < ndon;
                     const float t_mid = 0.5f * (t_cur + t_end);
-                    // first split of a ray: remember it for k_merge_list
-                    const bool first = donor && !shared;
-                    const unsigned long long fm = __ballot(first);
-                    if (fm) {
-                        unsigned long long lb = 0;
-                        if (lane == 0) lb = atomicAdd(C->nsplit, (unsigned long long)__popcll(fm));
-                        lb = shfl_u64(lb, 0);
-                        if (first) split_list[lb + __popcll(fm & ((1ull << lane) - 1ull))] = (uint32_t)r;
-                    }
+                    // a split ray's outputs are written from its merge key afterwards (k_merge_flags / k_rank): mark it
+                    if (donor) split_flag[r] = 1;
                     // receiver side: the q-th idle lane takes the q-th donor's far half
                     const int irank = __popcll(im & ((1ull << lane) - 1ull));
                     const bool recv = !busy && irank < ndon;
@@ -979,27 +971,36 @@ extern "C" int vx_debug_trace_util(unsigned long long* out24, int reset)
 namespace vx {
 #endif
 
-// outputs of the rays that were split by work donation, from their merged keys
-__global__ __launch_bounds__(256) void k_merge_list(const uint32_t* __restrict__ list, const unsigned long long* __restrict__ nlist,
-                                                    const unsigned long long* __restrict__ keys, float* __restrict__ t_out,
-                                                    unsigned long long* __restrict__ idx_out, uint8_t* __restrict__ shadowed_out)
+// Outputs of the rays that were split by work donation, from their merged keys.  The flags are read four rays at a time and
+// cleared on the way (they must be all zero for the next launch).  Used when k_rank does not run; k_rank does the same itself.
+__global__ __launch_bounds__(256) void k_merge_flags(uint8_t* __restrict__ flags, uint64_t nrays, const unsigned long long* __restrict__ keys,
+                                                     float* __restrict__ t_out, unsigned long long* __restrict__ idx_out, uint8_t* __restrict__ shadowed_out)
 {
-    const unsigned long long n = *nlist;
-    for (unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256u) {
-        const uint32_t r = list[i];
-        const unsigned long long k = keys[r];
-        if (t_out) t_out[r] = k == ~0ull ? -1.0f : __uint_as_float((uint32_t)(k >> 32));
-        if (idx_out) idx_out[r] = k == ~0ull ? ~0ull : (k & 0xFFFFFFFFull);
-        if (shadowed_out) shadowed_out[r] = k == ~0ull ? 0 : 1;
+    const uint64_t nquads = (nrays + 3) / 4;
+    uint32_t* f4 = reinterpret_cast<uint32_t*>(flags);  // the buffer is padded to a multiple of 4 bytes
+    for (uint64_t q = (uint64_t)blockIdx.x * 256u + threadIdx.x; q < nquads; q += (uint64_t)gridDim.x * 256u) {
+        const uint32_t w = f4[q];
+        if (!w) continue;
+        f4[q] = 0u;
+        for (uint32_t k = 0; k < 4u; ++k) {
+            if (!((w >> (8u * k)) & 0xFFu)) continue;
+            const uint64_t r = q * 4u + k;
+            if (r >= nrays) break;
+            const unsigned long long key = keys[r];
+            if (t_out) t_out[r] = key == ~0ull ? -1.0f : __uint_as_float((uint32_t)(key >> 32));
+            if (idx_out) idx_out[r] = key == ~0ull ? ~0ull : (key & 0xFFFFFFFFull);
+            if (shadowed_out) shadowed_out[r] = key == ~0ull ? 0 : 1;
+        }
     }
 }
 
 // Per-ray post-pass over all rays: primitive id (== gl_PrimitiveID: rank of the voxel in the ascending AABB list), the
 // cube-face normal of raytrace2.rchit:60-73, and wavefront hit compaction.
-__global__ __launch_bounds__(256) void k_rank(const float* __restrict__ t, const unsigned long long* __restrict__ idx, uint64_t nrays, GridParams g,
+__global__ __launch_bounds__(256) void k_rank(float* __restrict__ t, unsigned long long* __restrict__ idx, uint64_t nrays, GridParams g,
                                               const uint32_t* __restrict__ words, const uint32_t* __restrict__ word_prefix, const float* __restrict__ rays,
                                               const Camera* __restrict__ cam, uint32_t* __restrict__ prim_out, float* __restrict__ normal_out, vx_hit* __restrict__ hits,
-                                              unsigned long long* nhits)
+                                              unsigned long long* nhits, uint8_t* __restrict__ split_flag, const unsigned long long* __restrict__ keys,
+                                              uint8_t* __restrict__ shadowed_out)
 {
     const uint64_t r = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     const bool active = r < nrays;
@@ -1007,7 +1008,16 @@ __global__ __launch_bounds__(256) void k_rank(const float* __restrict__ t, const
     uint32_t prim = 0xFFFFFFFFu;
     if (active) {
         tt = t[r];
-        const unsigned long long i = idx[r];
+        unsigned long long i = idx[r];
+        if (split_flag && split_flag[r]) {  // a ray that was split by work donation: its result is the merge key (and the flag goes back to 0)
+            const unsigned long long key = keys[r];
+            tt = key == ~0ull ? -1.0f : __uint_as_float((uint32_t)(key >> 32));
+            i = key == ~0ull ? ~0ull : (key & 0xFFFFFFFFull);
+            t[r] = tt;
+            idx[r] = i;
+            if (shadowed_out) shadowed_out[r] = key == ~0ull ? 0 : 1;
+            split_flag[r] = 0;
+        }
         float n0 = 0.0f, n1 = 0.0f, n2 = 0.0f;
         if (i != ~0ull) {
             const uint64_t wi = i >> 5;
@@ -1054,15 +1064,15 @@ __global__ __launch_bounds__(256) void k_rank(const float* __restrict__ t, const
     }
 }
 
-size_t trace_spill_bytes(uint64_t nrays) { return (size_t)nrays * sizeof(uint32_t) + 64; }  // list of split rays
+size_t trace_spill_bytes(uint64_t nrays) { return (size_t)nrays + 64; }  // one flag byte per ray: split by work donation
 
 void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* word_prefix, const TraceIO& io, unsigned long long* counters /*>= 4*/,
                   unsigned long long* idx_tmp, void* spill_buf, unsigned long long* keys, hipStream_t s)
 {
     const uint64_t nrays = io.nrays;
     if (!nrays) return;
-    // counters[0]: work counter, [1]: number of rays split by work donation
-    (void)hipMemsetAsync(counters, 0, 2 * sizeof(unsigned long long), s);
+    // counters[0]: work counter
+    (void)hipMemsetAsync(counters, 0, sizeof(unsigned long long), s);
     const uint64_t n1 = (uint64_t)mips.d1[0] * mips.d1[1] * mips.d1[2];
     const uint32_t m1_words = (uint32_t)((n1 + 31) / 32);
     const bool lds_m1 = (size_t)m1_words * 4 <= 40960;  // 4 workgroups x 40 KiB fit the CU's 160 KiB
@@ -1080,10 +1090,10 @@ void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* wo
     const uint32_t m2_words = (uint32_t)((n2 + 31) / 32);
     const size_t shmem = lds_m1 ? (size_t)(m1_words + m2_words) * 4 : 0;
     // intra-wave work donation in the drain phase (default on; VOXHIP_TRACE_DONATE=0 disables).  The merge key holds the
-    // voxel index in 32 bits and the list holds ray numbers in 32 bits.
+    // voxel index in 32 bits.  spill_buf: one flag byte per ray, all zero on entry (the caller zeroes a new buffer) and on exit.
     static const int env_donate = getenv("VOXHIP_TRACE_DONATE") ? atoi(getenv("VOXHIP_TRACE_DONATE")) : 1;
     const bool donate = env_donate && spill_buf && keys && g.nvox <= 0x100000000ull && nrays < 0xFFFFFFFFull;
-    uint32_t* dlist = donate ? (uint32_t*)spill_buf : nullptr;
+    uint8_t* flags = donate ? (uint8_t*)spill_buf : nullptr;
     if (donate) (void)hipMemsetAsync(keys, 0xFF, (size_t)nrays * 8, s);  // "no hit" in every ray's merge key
     TraceParams P;
     std::memset(&P, 0, sizeof(P));
@@ -1102,15 +1112,17 @@ void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* wo
     P.cold.idx_out = idx_out;
     P.cold.shadowed_out = io.shadowed_out;
     P.cold.next_item = counters;
-    P.cold.nsplit = counters + 1;
     P.cold.keys = keys;
-    P.cold.split_list = dlist;
+    P.cold.split_flag = flags;
     if (lds_m1) { VX_KL(k_trace<true>, grid, block, shmem, s, P); } else { VX_KL(k_trace<false>, grid, block, shmem, s, P); }
-    if (donate) VX_KL(k_merge_list, dim3(256), block, 0, s, dlist, counters + 1, keys, io.t_out, idx_out, io.shadowed_out);
     if (want_rank) {
         if (io.hits && io.nhits) (void)hipMemsetAsync(io.nhits, 0, sizeof(unsigned long long), s);
         const dim3 rgrid((unsigned)((nrays + 255) / 256));
-        VX_KL(k_rank, rgrid, block, 0, s, io.t_out, idx_tmp, nrays, g, mips.w0, word_prefix, io.rays, io.cam_dev, io.prim_out, io.normal_out, io.hits, io.nhits);
+        VX_KL(k_rank, rgrid, block, 0, s, io.t_out, idx_tmp, nrays, g, mips.w0, word_prefix, io.rays, io.cam_dev, io.prim_out, io.normal_out, io.hits, io.nhits,
+              flags, keys, io.shadowed_out);
+    } else if (donate) {
+        const uint64_t nq = (nrays + 3) / 4;
+        VX_KL(k_merge_flags, dim3((unsigned)((nq + 255) / 256 > 4096 ? 4096 : (nq + 255) / 256)), block, 0, s, flags, nrays, keys, io.t_out, idx_out, io.shadowed_out);
     }
 }
 
