@@ -107,10 +107,9 @@ def main():
     desc = grid.describe()
     nwords = desc["num_words"]
     wb, we, chunk = voxhip.shard_words(nwords, rank, world)
-    cap = max(desc["occupied"], 1) if world == 1 else None
-    if world > 1:
-        # the unsharded occupancy count sizes the AABB buffer; the timed loop rebuilds the mask from shards
-        cap = max(desc["occupied"], 1)
+    # capacity of the getAabbs output: the whole list (VoxelGridVec keeps one Aabb per setVoxel call, duplicates included;
+    # the Bool flavour one per occupied voxel -- for N > 1 the unsharded count, the timed loop rebuilds the mask from shards)
+    cap = max(desc["set_calls"] if kind == voxhip.GRID_VEC else desc["occupied"], 1)
     d_aabbs = torch.empty(cap * 6, dtype=torch.float32, device=dev)
     gathered = torch.empty(chunk * world, dtype=torch.int32, device=dev) if world > 1 else None
 
