@@ -742,6 +742,22 @@ __global__ __launch_bounds__(256, 4 /*waves per SIMD: keeps the allocation at <=
 #ifdef VX_TRACE_DEBUG_CYCLES
     unsigned long long dbg_t0 = 0;
 #endif
+    // The first chunk of every wave is assigned statically: thousands of waves asking the one counter in the same microsecond
+    // queue up behind each other at the memory-side atomic unit.
+    uint64_t static_rays;
+    {
+        const ColdPtr C = cold_params();
+        const uint64_t nrays = C->nrays;
+        uint64_t csz = nrays / (8ull * gridDim.x);
+        csz = csz > (uint64_t)kChunkMax ? (uint64_t)kChunkMax : csz;
+        csz = csz < (uint64_t)kChunkRays ? (uint64_t)kChunkRays : (csz & ~63ull);
+        static_rays = csz * 4ull * gridDim.x;
+        chunk_cur = csz * (4ull * blockIdx.x + (threadIdx.x >> 6));
+        chunk_end = chunk_cur + csz;
+        if (chunk_end > nrays) chunk_end = nrays;
+        if (chunk_cur > chunk_end) chunk_cur = chunk_end;
+        if (static_rays >= nrays) drained_global = true;
+    }
     for (;;) {
         const unsigned long long busy_mask = __ballot(busy);
         const int nbusy = __popcll(busy_mask);
@@ -765,7 +781,7 @@ __global__ __launch_bounds__(256, 4 /*waves per SIMD: keeps the allocation at <=
                 csz = csz < (uint64_t)kChunkRays ? (uint64_t)kChunkRays : (csz & ~63ull);
                 unsigned long long base = 0;
                 if (lane == 0) base = atomicAdd(C->next_item, (unsigned long long)csz);
-                base = shfl_u64(base, 0);
+                base = shfl_u64(base, 0) + static_rays;  // the counter runs behind the statically assigned first chunks
                 second = base;
                 chunk_cur = base + (need - take);
                 chunk_end = base + csz;
