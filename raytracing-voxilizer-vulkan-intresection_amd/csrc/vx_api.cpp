@@ -325,7 +325,7 @@ vx_status setup_finish(uint32_t ntri, DevBuf& ubase, DevBuf& btri, Mail* mail, h
     *total_units = tot;
     if (tot) {
         VX_HIP(btri.ensure((size_t)(tot / 256 + 2) * 4));
-        vx::launch_unit_blocks(ubase.as<uint32_t>(), ntri, btri.as<uint32_t>(), s);
+        vx::launch_unit_blocks(ubase.as<uint32_t>(), ntri, (uint32_t)tot, btri.as<uint32_t>(), s);
     }
     return VX_OK;
 }

@@ -567,20 +567,30 @@ __device__ __forceinline__ TriRec load_rec(const TriRec* __restrict__ recs, uint
 // ------------------------------------------------------------------------------------------------------------
 constexpr uint32_t kStageTris = 192;
 
+// One thread per 256-unit block: binary search of the unit bases for the triangle that owns the block's first unit (the
+// largest t with unit_base[t] <= 256 b; triangles without units share their base with the next one and are skipped by taking
+// the LAST such t).  The previous form -- one thread per triangle writing the blocks it spans -- serialised on the few
+// triangles that span hundreds of blocks.
 __global__ __launch_bounds__(256) void k_unit_blocks(const uint32_t* __restrict__ unit_base, uint32_t ntri, uint32_t* __restrict__ block_tri)
 {
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= ntri) return;
-    const uint32_t b0 = unit_base[t], b1 = unit_base[t + 1];
-    if (b1 <= b0) return;
-    const uint32_t k0 = (b0 + 255u) >> 8, k1 = (b1 - 1u) >> 8;
-    for (uint32_t k = k0; k <= k1 && k >= k0; ++k) block_tri[k] = t;
+    const uint32_t U = unit_base[ntri];
+    const uint32_t nUB = (U + 255u) >> 8;
+    const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+    if (b >= nUB) return;
+    const uint32_t u = b << 8;
+    uint32_t lo = 0, hi = ntri;  // unit_base[lo] <= u < unit_base[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (unit_base[mid] <= u) lo = mid; else hi = mid;
+    }
+    block_tri[b] = lo;
 }
 
-void launch_unit_blocks(const uint32_t* unit_base, uint32_t ntri, uint32_t* block_tri, hipStream_t s)
+void launch_unit_blocks(const uint32_t* unit_base, uint32_t ntri, uint32_t total_units, uint32_t* block_tri, hipStream_t s)
 {
-    if (!ntri) return;
-    VX_KL(k_unit_blocks, dim3((ntri + 255) / 256), dim3(256), 0, s, unit_base, ntri, block_tri);
+    const uint32_t nUB = (total_units + 255u) >> 8;
+    if (!ntri || !nUB) return;
+    VX_KL(k_unit_blocks, dim3((nUB + 255) / 256), dim3(256), 0, s, unit_base, ntri, block_tri);
 }
 
 struct UnitStage {
