@@ -1104,7 +1104,7 @@ vx_status vx_octree_build(const vx_mesh* mesh_c, float vs, uint64_t max_items, v
                               nullptr, unsorted.as<uint64_t>(), s);
         const size_t tb = vx::sort_tmp_bytes(hits);
         OCT_HIP(sorttmp.ensure(tb));
-        vx::launch_sort_u64(unsorted.as<uint64_t>(), o->items.as<uint64_t>(), hits, (int)(3 * o->bits ? 3 * o->bits : 1), sorttmp.p, tb, s);  // octTree.hpp:363
+        vx::launch_sort_u64(unsorted.as<uint64_t>(), o->items.as<uint64_t>(), hits, o->bits ? (int)(3 * o->bits) : 1, sorttmp.p, tb, s);  // octTree.hpp:363
     }
     // node array: breadth-first expansion + pre-order renumbering on the device (octTree.hpp:319-358, :371)
     OCT_HIP(vx::build_octree_nodes(o->items.as<uint64_t>(), (uint32_t)hits, o->bits, max_items, &o->dnodes, &o->nnodes, s));

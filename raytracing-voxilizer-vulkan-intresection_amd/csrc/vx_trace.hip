@@ -493,7 +493,6 @@ __device__ __forceinline__ bool upper_step(Lane& R, const GridParams& g, const T
     const bool ey = !ex && (R.tMy <= R.tMz);
     const float t_o = sel3(ex, ey, R.tMx, R.tMy, R.tMz);
     const int sx = R.dx < 0.0f ? -1 : 1, sy = R.dy < 0.0f ? -1 : 1, sz = R.dz < 0.0f ? -1 : 1;
-    const float tauS = R.taux + R.tauy + R.tauz;
     if (R.fresh) {
         // forward near-ties (other axes' next planes), backward near-ties (planes just behind) -> per-axis offset sets
         const float tau_exit = sel3(ex, ey, R.taux, R.tauy, R.tauz);
