@@ -8,14 +8,14 @@
 // exact float box the reference would have built for it -- so the reported t is the very float the brute-force minimum
 // yields.
 //
-// Data layout for traversal (built once per grid by k_build_bricks / k_build_coarse, the analogue of the reference's BLAS
-// build, hello_vulkan.cpp:737-760):
-//   level 0  "bricks": the bitmask re-tiled brick-major -- one uint64 per (8x8x8 brick, z slice), bit = (y&7)*8 + (x&7).  A
-//            lane keeps the slice it is walking in two registers, so a whole slice of cells costs ONE dependent 8-byte load
-//            instead of one load per cell (the kernel is latency-bound: measured 47 % of wave cycles in s_waitcnt with the
+// Data layout for traversal (built once per bitmask by k_build_bricks / k_brick_bounds / k_build_mip2, the analogue of the
+// reference's BLAS build, hello_vulkan.cpp:737-760):
+//   level 0  "bricks": the bitmask re-tiled brick-major -- one uint64 per (8x8x8 brick, z slice), bit = (y&7)*8 + (x&7), plus
+//            a packed box of the brick's occupied cells.  A whole slice of cells costs ONE dependent 8-byte load instead of
+//            one load per cell (the kernel is latency-bound: measured 47 % of wave cycles in s_waitcnt with the
 //            reference-layout bitmask).
 //   level 1  one bit per brick, x-fastest; staged in LDS by every workgroup when it fits (32 KiB at 512^3).
-//   level 2  one bit per 8^3 bricks; a few hundred bytes, read through L1/L2.
+//   level 2  one bit per 8^3 bricks; a few hundred bytes, behind level 1 in LDS.
 //
 // Conservative enumeration.  A cell's float box differs from the nominal lattice planes by a few ulps of the largest
 // coordinate.  Whenever two plane crossings are closer in t than that tolerance (per axis tau = tol_pos * |1/d|) the cells
@@ -23,12 +23,14 @@
 // crossed).  Such neighbours are never walked -- the nominal ray does not pass through them -- only tested (level 0) or
 // OR-ed into the "descend?" decision (upper levels); the walk always descends into the nominal cell and reaches the
 // neighbours' children through the child level's own probes.  Traversal stops once the exit time of the current cell
-// exceeds the best hit by more than the tolerance.
+// exceeds the best hit by more than the tolerance of the ray's major axis.
 //
-// Wave efficiency.  One flat loop per lane: every iteration is a single DDA step at the lane's current level (descend /
-// advance / pop; the parent's state is recomputed on pop instead of being kept in registers).  Waves are persistent and
-// lanes whose ray has finished pull the next ray from a global counter, so rays of very different path lengths do not
-// leave most of a wave idle.
+// Wave efficiency.  Persistent waves; a lane whose ray has finished takes the next ray of its wave's chunk of a global queue
+// (first chunk static, later ones by one atomicAdd of a guided size).  A round alternates two phases so that the lanes run
+// the same code together: upper-level walk steps (look at a cell / descend / advance / leave the block), then the brick
+// test of every lane that posted an occupied brick (bit-parallel: slices x rows x candidate mask, exact slab test on the
+// survivors).  Once the queue is dry, lanes with a long interval left hand its far half to idle lanes of their wave; the
+// pieces meet in a 64-bit atomicMin per ray.  DESIGN.md section 4 has the measured history and what did not work.
 //
 // No MFMA: this is traversal, not a contraction.  Algorithmic HBM traffic is the ray stream (24 B in, 4-8 B out per ray).
 #include "vx_internal.h"
