@@ -1027,13 +1027,13 @@ __global__ __launch_bounds__(256) void k_merge_flags(uint8_t* __restrict__ flags
 
 // Per-ray post-pass over all rays: primitive id (== gl_PrimitiveID: rank of the voxel in the ascending AABB list), the
 // cube-face normal of raytrace2.rchit:60-73, and wavefront hit compaction.
-__global__ __launch_bounds__(256) void k_rank(float* __restrict__ t, unsigned long long* __restrict__ idx, uint64_t nrays, GridParams g,
+__global__ __launch_bounds__(1024) void k_rank(float* __restrict__ t, unsigned long long* __restrict__ idx, uint64_t nrays, GridParams g,
                                               const uint32_t* __restrict__ words, const uint32_t* __restrict__ word_prefix, const float* __restrict__ rays,
                                               const Camera* __restrict__ cam, uint32_t* __restrict__ prim_out, float* __restrict__ normal_out, vx_hit* __restrict__ hits,
                                               unsigned long long* nhits, uint8_t* __restrict__ split_flag, const unsigned long long* __restrict__ keys,
                                               uint8_t* __restrict__ shadowed_out)
 {
-    const uint64_t r = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = r < nrays;
     float tt = -1.0f;
     uint32_t prim = 0xFFFFFFFFu;
@@ -1079,18 +1079,27 @@ __global__ __launch_bounds__(256) void k_rank(float* __restrict__ t, unsigned lo
         if (normal_out) { normal_out[3 * r] = n0; normal_out[3 * r + 1] = n1; normal_out[3 * r + 2] = n2; }
     }
     if (hits) {
+        // Compaction: ONE touch of the global counter per workgroup (launched with 1024 threads for this).  One per wave meant
+        // 15 600 returning atomics on one address for 1M rays, ~10 ns each at the memory-side atomic unit: 196 us instead of 23.
+        __shared__ unsigned wcnt[16];
+        __shared__ unsigned long long bbase;
         const bool hit = active && prim != 0xFFFFFFFFu;
         const unsigned long long bal = __ballot(hit);
-        if (bal) {
-            const int lane = threadIdx.x & 63;
-            unsigned long long hb = 0;
-            if (lane == 0) hb = atomicAdd(nhits, (unsigned long long)__popcll(bal));
-            hb = ((unsigned long long)__shfl((unsigned)(hb >> 32), 0, 64) << 32) | __shfl((unsigned)hb, 0, 64);
-            if (hit) {
-                vx_hit h;
-                h.ray = (uint32_t)r; h.prim = prim; h.t = tt;
-                hits[hb + __popcll(bal & ((1ull << lane) - 1ull))] = h;
-            }
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
+        if (lane == 0) wcnt[wv] = (unsigned)__popcll(bal);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned tot = 0;
+            for (int w = 0; w < nw; ++w) tot += wcnt[w];
+            bbase = tot ? atomicAdd(nhits, (unsigned long long)tot) : 0ull;
+        }
+        __syncthreads();
+        if (hit) {
+            unsigned long long off = bbase;
+            for (int w = 0; w < wv; ++w) off += wcnt[w];
+            vx_hit h;
+            h.ray = (uint32_t)r; h.prim = prim; h.t = tt;
+            hits[off + __popcll(bal & ((1ull << lane) - 1ull))] = h;
         }
     }
 }
@@ -1148,8 +1157,9 @@ void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* wo
     if (lds_m1) { VX_KL(k_trace<true>, grid, block, shmem, s, P); } else { VX_KL(k_trace<false>, grid, block, shmem, s, P); }
     if (want_rank) {
         if (io.hits && io.nhits) (void)hipMemsetAsync(io.nhits, 0, sizeof(unsigned long long), s);
-        const dim3 rgrid((unsigned)((nrays + 255) / 256));
-        VX_KL(k_rank, rgrid, block, 0, s, io.t_out, idx_tmp, nrays, g, mips.w0, word_prefix, io.rays, io.cam_dev, io.prim_out, io.normal_out, io.hits, io.nhits,
+        const unsigned rthreads = io.hits ? 1024u : 256u;  // the hit list's compaction touches the global counter once per workgroup
+        const dim3 rgrid((unsigned)((nrays + rthreads - 1) / rthreads)), rblock(rthreads);
+        VX_KL(k_rank, rgrid, rblock, 0, s, io.t_out, idx_tmp, nrays, g, mips.w0, word_prefix, io.rays, io.cam_dev, io.prim_out, io.normal_out, io.hits, io.nhits,
               flags, keys, io.shadowed_out);
     } else if (donate) {
         const uint64_t nq = (nrays + 3) / 4;
