@@ -369,14 +369,6 @@ __global__ __launch_bounds__(kOneBlock) void k_scan_onepass(const uint32_t* __re
             prefix_s = excl;
             if (tile == ntiles - 1 && total) *total = excl + (unsigned long long)btot;
         }
-        // self-cleaning: the tile that finishes its look-back last (nobody reads a state word any more) zeroes the ticket, the
-        // counter and every state word, so the next scan on this buffer needs no memset
-        unsigned long long fin = 0;
-        if (lane == 0) fin = atomicAdd(&status[1], 1ull);
-        fin = shfl_u64_k(fin, 0);
-        if (fin == (unsigned long long)ntiles - 1ull) {
-            for (uint32_t i = lane; i < ntiles + 2u; i += 64u) __hip_atomic_store(&status[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
     }
     __syncthreads();
     pre += (unsigned)prefix_s;
@@ -392,6 +384,17 @@ __global__ __launch_bounds__(kOneBlock) void k_scan_onepass(const uint32_t* __re
         for (int j = 0; j < kOneItems; ++j) {
             if (base + j <= n) out[base + j] = pre;
             pre += v[j];
+        }
+    }
+    // self-cleaning: the tile that finishes its look-back last (nobody reads a state word any more) zeroes the ticket, the
+    // counter and every state word, so the next scan on this buffer needs no memset.  Last thing the workgroup does: the
+    // counter's old value takes microseconds to come back and nothing else has to wait for it.
+    if (threadIdx.x < 64) {
+        unsigned long long fin = 0;
+        if (lane == 0) fin = atomicAdd(&status[1], 1ull);
+        fin = shfl_u64_k(fin, 0);
+        if (fin == (unsigned long long)ntiles - 1ull) {
+            for (uint32_t i = lane; i < ntiles + 2u; i += 64u) __hip_atomic_store(&status[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
