@@ -449,6 +449,22 @@ def test_random_soups_property(gpu):
             assert np.array_equal(tt, ot) and np.array_equal(pp, op), "case %d rays" % case
 
 
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 256, 257, 1023, 4097])
+def test_tiny_ray_batches(gpu, n):
+    """Batch sizes around the wave / workgroup / chunk boundaries of the persistent ray kernel (static first chunk, guided
+    chunk size, drain phase from the first round on), with and without the compacted hit list."""
+    v, t = vx_scenes.scene("rotcube")
+    vs = np.float32(0.09)
+    g = gpu.Grid.voxelize(gpu.Mesh.from_arrays(v, t), vs)
+    ow, _, gi = oracle.build_bool(v, t, vs)
+    oa = oracle.bool_aabbs(ow, gi, vs)
+    rays = vx_scenes.random_rays(n, gi["bmin"], gi["bmax"], seed=1000 + n)
+    check_trace(gpu, g, oa, rays)
+    tt, nh = g.trace(rays, want_prim=False)   # no primitive ids: the split rays are merged by k_merge_flags instead of k_rank
+    ot, _ = oracle.trace_brute(oa, rays)
+    assert np.array_equal(tt, ot) and nh == int((ot > 0).sum())
+
+
 def test_far_from_origin(gpu):
     """Meshes far from the origin (coordinates 1e2..2e3 x their own size): float32 spacing is then a visible fraction of a voxel.
     The voxelizer must still match bit for bit (same roundings as the reference), and the ray kernel's tolerance, which scales
