@@ -54,7 +54,15 @@ typedef enum vx_grid_kind {
     VX_GRID_VEC = 2         /* VoxelGridVec         voxelgridVecEncoding.{hpp,cpp} */
 } vx_grid_kind;
 
-typedef struct vx_mesh vx_mesh;     /* parsed OBJ: what VoxelBuilder keeps in m_attribs / m_shapes */
+/* MaterialObj (common/obj_loader.h:32-52) as VoxelBuilder copies it out of tinyobj::material_t (VoxelBuilder.hpp:383-394) */
+typedef struct vx_material {
+    float ambient[3], diffuse[3], specular[3], transmittance[3], emission[3];
+    float shininess, ior, dissolve;
+    int32_t illum;
+    int32_t texture_id;
+} vx_material;
+
+typedef struct vx_mesh vx_mesh;     /* parsed OBJ: what VoxelBuilder keeps in m_attribs / m_shapes / m_materials */
 typedef struct vx_grid vx_grid;     /* a VoxelGrid<T> */
 typedef struct vx_octree vx_octree; /* an Octree */
 
@@ -101,9 +109,20 @@ size_t vx_mesh_num_triangles(const vx_mesh* m);
 /* host copies (NULL for vx_mesh_from_device meshes) */
 const float* vx_mesh_host_vertices(const vx_mesh* m);
 const int32_t* vx_mesh_host_indices(const vx_mesh* m);
+/* materials: what tinyobj hands VoxelBuilder as GetMaterials() and shape.mesh.material_ids (VoxelBuilder.hpp:69,375-381):
+ * the records of the OBJ's mtllib files in file order and one id per triangle (-1 = none).  vx_mesh_set_materials attaches
+ * the same to a mesh built from arrays (ids are copied; pass NULL ids for "no face has a material"). */
+size_t vx_mesh_num_materials(const vx_mesh* m);
+vx_status vx_mesh_materials(const vx_mesh* m, vx_material* out, size_t capacity);
+const int32_t* vx_mesh_host_material_ids(const vx_mesh* m); /* num_triangles entries; NULL when the mesh has no materials */
+vx_status vx_mesh_set_materials(vx_mesh* m, const vx_material* materials, size_t num_materials, const int32_t* tri_material_ids);
 void vx_mesh_free(vx_mesh* m);
 
-/* ---- voxelize: replaces VoxelBuilder<T,inParaell>::buildVoxelGrid (VoxelBuilder.hpp:338-542) --------------- */
+/* ---- voxelize: replaces VoxelBuilder<T,inParaell>::buildVoxelGrid (VoxelBuilder.hpp:338-542) ---------------
+ * Limits (the reference has none besides memory): at most 65535 cells per axis (the per-triangle candidate ranges are kept
+ * as 16-bit start/count pairs) and 2^37 cells in total; beyond either the call fails with VX_ERR_CAPACITY -- also for
+ * vx_octree_build, where the reference itself stops at 2^21 cells per axis with the Morton-bits error (octTree.hpp:583-585;
+ * that message is reported as VX_ERR_MORTON_BITS only for axes the 65535 limit lets through, i.e. never today). */
 vx_status vx_voxelize(const vx_mesh* mesh, float voxel_size, vx_grid_kind kind, const vx_voxelize_opts* opts /*NULL ok*/,
                       vx_grid** out);
 /* same, re-using an existing grid handle's device buffers (steady-state loops; no allocation when sizes repeat) */

@@ -13,7 +13,8 @@
 #pragma clang fp contract(off)
 
 namespace vx {
-int load_obj(const char* path, std::vector<float>& verts, std::vector<int32_t>& tris, std::string& msg);
+int load_obj(const char* path, std::vector<float>& verts, std::vector<int32_t>& tris, std::vector<int32_t>& tri_mat, std::vector<vx_material>& mats,
+             std::string& msg);
 }
 
 namespace {
@@ -39,11 +40,22 @@ vx_status fail(vx_status s, const std::string& m)
     } while (0)
 
 // ---- pooled device memory: hipMalloc/hipFree are slow and synchronising, steady-state loops must not call them ----
+// The pool is STREAM-ORDERED: a block goes back on the free list together with the stream its owner queued work on and an
+// event recorded on that stream at the moment of the release.  It is handed out again at once to a request from the SAME
+// stream (work queued later on that stream runs after the old owner's kernels), and to any other stream only once the
+// event has completed -- so a block that kernels in flight still read or write is never given to a different handle
+// (distinct handles on distinct threads with per-handle streams are allowed by voxhip.h).
 constexpr int kMaxDev = 16;
+struct FreeBlock {
+    void* p;
+    hipStream_t stream;
+    hipEvent_t ev;  // null: nothing was in flight (never used, or released after a synchronize)
+};
 struct Pool {
     std::mutex mu;
-    std::multimap<size_t, void*> free_blocks;
+    std::multimap<size_t, FreeBlock> free_blocks;
     std::unordered_map<void*, size_t> live;
+    std::vector<hipEvent_t> spare_events;
 };
 Pool g_pool[kMaxDev];
 
@@ -56,15 +68,17 @@ size_t round_size(size_t b)
     return p;
 }
 
-hipError_t pool_alloc(int dev, size_t bytes, void** out)
+hipError_t pool_alloc(int dev, size_t bytes, void** out, hipStream_t stream)
 {
     const size_t sz = round_size(bytes);
     Pool& P = g_pool[dev];
     {
         std::lock_guard<std::mutex> lk(P.mu);
-        auto it = P.free_blocks.lower_bound(sz);
-        if (it != P.free_blocks.end() && it->first <= sz * 2) {
-            *out = it->second;
+        for (auto it = P.free_blocks.lower_bound(sz); it != P.free_blocks.end() && it->first <= sz * 2; ++it) {
+            FreeBlock& fb = it->second;
+            if (fb.ev && fb.stream != stream && hipEventQuery(fb.ev) != hipSuccess) continue;  // still in flight on another stream
+            if (fb.ev) P.spare_events.push_back(fb.ev);
+            *out = fb.p;
             P.live[*out] = it->first;
             P.free_blocks.erase(it);
             return hipSuccess;
@@ -84,14 +98,29 @@ hipError_t pool_alloc(int dev, size_t bytes, void** out)
     return hipSuccess;
 }
 
-void pool_free(int dev, void* p)
+// `in_flight`: work that touches the block may still be queued on `stream` (false: the caller has synchronized)
+void pool_free(int dev, void* p, hipStream_t stream, bool in_flight)
 {
     if (!p) return;
     Pool& P = g_pool[dev];
+    hipEvent_t ev = nullptr;
+    if (in_flight) {
+        {
+            std::lock_guard<std::mutex> lk(P.mu);
+            if (!P.spare_events.empty()) { ev = P.spare_events.back(); P.spare_events.pop_back(); }
+        }
+        if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
+        if (!ev || hipEventRecord(ev, stream) != hipSuccess) {
+            // no event to order the reuse by: fall back to waiting for the stream
+            (void)hipStreamSynchronize(stream);
+            if (ev) { std::lock_guard<std::mutex> lk(P.mu); P.spare_events.push_back(ev); }
+            ev = nullptr;
+        }
+    }
     std::lock_guard<std::mutex> lk(P.mu);
     auto it = P.live.find(p);
-    if (it == P.live.end()) return;
-    P.free_blocks.emplace(it->second, p);
+    if (it == P.live.end()) { if (ev) P.spare_events.push_back(ev); return; }
+    P.free_blocks.emplace(it->second, FreeBlock{p, stream, ev});
     P.live.erase(it);
 }
 
@@ -99,18 +128,19 @@ struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
     int dev = 0;
+    hipStream_t stream = nullptr;  // the stream the owner queues this buffer's work on (set by the owning handle)
     bool fresh = false;  // set when ensure() handed out a new block (contents undefined); the owner clears it
     hipError_t ensure(size_t bytes)
     {
         if (bytes <= cap && p) return hipSuccess;
         release();
-        hipError_t e = pool_alloc(dev, bytes, &p);
+        hipError_t e = pool_alloc(dev, bytes, &p, stream);
         if (e == hipSuccess) { cap = round_size(bytes); fresh = true; }
         return e;
     }
-    void release()
+    void release(bool in_flight = true)
     {
-        if (p) pool_free(dev, p);
+        if (p) pool_free(dev, p, stream, in_flight);
         p = nullptr;
         cap = 0;
     }
@@ -193,6 +223,8 @@ struct vx_mesh {
     int device = 0;
     std::vector<float> hv;
     std::vector<int32_t> hi;
+    std::vector<int32_t> tri_mat;        // material id per triangle (-1 = none); empty: the mesh has no materials
+    std::vector<vx_material> materials;  // m_materials of the reference builder (VoxelBuilder.hpp:69)
     size_t nv = 0, nt = 0;
     const float* dv = nullptr;
     const int32_t* di = nullptr;
@@ -218,6 +250,13 @@ struct vx_grid {
     {
         device = d;
         for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &bbounds, &idxtmp, &ttmp, &spill, &keys, &camera, &wprefix, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec}) b->dev = d;
+    }
+    // the stream this handle queues work on; the pool orders the reuse of released blocks by it
+    void set_stream(hipStream_t st)
+    {
+        if (st != stream && words.p) (void)hipStreamSynchronize(stream);  // work queued on the old stream must not outlive the switch
+        stream = st;
+        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &bbounds, &idxtmp, &ttmp, &spill, &keys, &camera, &wprefix, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec}) b->stream = st;
     }
     void release_all()
     {
@@ -456,7 +495,7 @@ vx_status vx_release_cached_memory(void)
 {
     int n = vx_device_count();
     for (int d = 0; d < n && d < kMaxDev; ++d) {
-        std::vector<void*> blocks;
+        std::vector<FreeBlock> blocks;
         {
             std::lock_guard<std::mutex> lk(g_pool[d].mu);
             for (auto& kv : g_pool[d].free_blocks) blocks.push_back(kv.second);
@@ -464,7 +503,11 @@ vx_status vx_release_cached_memory(void)
         }
         if (blocks.empty()) continue;
         DeviceGuard dg(d);
-        for (void* p : blocks) (void)hipFree(p);
+        for (FreeBlock& fb : blocks) {
+            if (fb.ev) (void)hipEventSynchronize(fb.ev);  // hipFree of a block that queued kernels still use would be the same race
+            (void)hipFree(fb.p);
+            if (fb.ev) { std::lock_guard<std::mutex> lk(g_pool[d].mu); g_pool[d].spare_events.push_back(fb.ev); }
+        }
     }
     return VX_OK;
 }
@@ -475,11 +518,12 @@ vx_status vx_mesh_load_obj(const char* path, vx_mesh** out)
     if (!path || !out) return fail(VX_ERR_INVALID_ARG, "null argument");
     vx_mesh* m = new vx_mesh();
     std::string msg;
-    const int rc = vx::load_obj(path, m->hv, m->hi, msg);
+    const int rc = vx::load_obj(path, m->hv, m->hi, m->tri_mat, m->materials, msg);
     if (rc == 1) { delete m; return fail(VX_ERR_PATH, "Path does not exist!"); }                                    // VoxelBuilder.hpp:54-56
     if (rc == 2) { delete m; return fail(VX_ERR_PARSE, "Colud not get valid reader! Error message " + msg); }        // :63-65
     m->nv = m->hv.size() / 3;
     m->nt = m->hi.size() / 3;
+    if (m->materials.empty()) m->tri_mat.clear();  // no mtllib: every id is -1
     m->device = g_device;
     *out = m;
     return VX_OK;
@@ -521,11 +565,37 @@ size_t vx_mesh_num_vertices(const vx_mesh* m) { return m ? m->nv : 0; }
 size_t vx_mesh_num_triangles(const vx_mesh* m) { return m ? m->nt : 0; }
 const float* vx_mesh_host_vertices(const vx_mesh* m) { return (m && !m->borrowed) ? m->hv.data() : nullptr; }
 const int32_t* vx_mesh_host_indices(const vx_mesh* m) { return (m && !m->borrowed) ? m->hi.data() : nullptr; }
+size_t vx_mesh_num_materials(const vx_mesh* m) { return m ? m->materials.size() : 0; }
+vx_status vx_mesh_materials(const vx_mesh* m, vx_material* out, size_t cap)
+{
+    if (!m || (!out && cap)) return fail(VX_ERR_INVALID_ARG, "null argument");
+    if (cap < m->materials.size()) return fail(VX_ERR_CAPACITY, "material buffer too small");
+    if (!m->materials.empty()) std::memcpy(out, m->materials.data(), m->materials.size() * sizeof(vx_material));
+    return VX_OK;
+}
+const int32_t* vx_mesh_host_material_ids(const vx_mesh* m) { return (m && !m->tri_mat.empty()) ? m->tri_mat.data() : nullptr; }
+vx_status vx_mesh_set_materials(vx_mesh* m, const vx_material* mats, size_t n, const int32_t* ids)
+{
+    if (!m || (n && !mats)) return fail(VX_ERR_INVALID_ARG, "null argument");
+    if (n > 32767) return fail(VX_ERR_CAPACITY, "more than 32767 materials: per-voxel ids are int16 (voxelgrid.hpp:29)");
+    if (ids)
+        for (size_t t = 0; t < m->nt; ++t)
+            if (ids[t] < -1 || (ids[t] >= 0 && (size_t)ids[t] >= n)) return fail(VX_ERR_INVALID_ARG, "material id out of range");
+    m->materials.assign(mats, mats + n);
+    if (ids && n) m->tri_mat.assign(ids, ids + m->nt); else m->tri_mat.clear();
+    return VX_OK;
+}
+
 void vx_mesh_free(vx_mesh* m)
 {
     if (!m) return;
-    m->bv.release();
-    m->bi.release();
+    if (m->uploaded) {
+        // grids on any stream may still be reading the vertex / index arrays: wait for the device before the blocks go back
+        DeviceGuard dg(m->device);
+        (void)hipDeviceSynchronize();
+    }
+    m->bv.release(/*in_flight=*/false);
+    m->bi.release(/*in_flight=*/false);
     delete m;
 }
 
@@ -541,7 +611,7 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
     VX_TRY(mesh_to_device(mesh));
     vx_voxelize_opts o{};
     if (opts) o = *opts;
-    g->stream = (hipStream_t)o.stream;
+    g->set_stream((hipStream_t)o.stream);
     hipStream_t s = g->stream;
     if (o.sat_variant != 0 && o.sat_variant != 1) return fail(VX_ERR_INVALID_ARG, "sat_variant must be 0 or 1");
 
@@ -695,7 +765,7 @@ vx_status vx_grid_create(vx_grid_kind kind, uint64_t x, uint64_t y, uint64_t z, 
     vx_grid* g = new vx_grid();
     g->kind = kind;
     g->set_dev(g_device);
-    g->stream = (hipStream_t)stream;
+    g->set_stream((hipStream_t)stream);
     const float zero[3] = {0.f, 0.f, 0.f};
     const uint64_t dim[3] = {x, y, z};
     fill_params(g->g, origin ? origin : zero, vs, dim);
@@ -745,6 +815,7 @@ vx_status vx_grid_set_voxel(vx_grid* g, uint64_t x, uint64_t y, uint64_t z)
         if (need > g->vec.cap) {
             DevBuf nb;
             nb.dev = g->device;
+            nb.stream = g->stream;
             VX_HIP(nb.ensure(need * 2));
             if (g->vec_count) VX_HIP(hipMemcpyAsync(nb.p, g->vec.p, (size_t)g->vec_count * sizeof(vx_aabb), hipMemcpyDeviceToDevice, g->stream));
             VX_HIP(hipStreamSynchronize(g->stream));
@@ -861,6 +932,7 @@ vx_status vx_grid_aabbs(const vx_grid* gc, vx_aabb* host_out, uint64_t cap, uint
     }
     DevBuf tmp;
     tmp.dev = g->device;
+    tmp.stream = g->stream;
     VX_HIP(tmp.ensure((size_t)m * sizeof(vx_aabb)));
     vx::launch_emit_bool_aabbs(g->words.as<uint32_t>(), g->wprefix.as<uint32_t>(), g->g, tmp.as<vx_aabb>(), m, g->stream);
     hipError_t e = hipMemcpyAsync(host_out, tmp.p, (size_t)m * sizeof(vx_aabb), hipMemcpyDeviceToHost, g->stream);
@@ -873,7 +945,7 @@ vx_status vx_grid_aabbs(const vx_grid* gc, vx_aabb* host_out, uint64_t cap, uint
 void vx_grid_free(vx_grid* g)
 {
     if (!g) return;
-    if (g->stream || true) { DeviceGuard dg(g->device); (void)hipStreamSynchronize(g->stream); }
+    { DeviceGuard dg(g->device); (void)hipStreamSynchronize(g->stream); }
     g->release_all();
     delete g;
 }
@@ -994,7 +1066,7 @@ vx_status vx_trace_ex(const vx_grid* gc, const vx_trace_args* args)
     const uint64_t n = io.nrays;
     if (!n) return VX_OK;
     DevBuf dr, dtm, dt, dp, dn, ds;
-    for (DevBuf* b : {&dr, &dtm, &dt, &dp, &dn, &ds}) b->dev = g->device;
+    for (DevBuf* b : {&dr, &dtm, &dt, &dp, &dn, &ds}) { b->dev = g->device; b->stream = g->stream; }
     auto rel = [&]() { for (DevBuf* b : {&dr, &dtm, &dt, &dp, &dn, &ds}) b->release(); };
     hipError_t e = hipSuccess;
     vx_status st = VX_OK;
@@ -1054,8 +1126,9 @@ vx_status vx_octree_build(const vx_mesh* mesh_c, float vs, uint64_t max_items, v
     o->vs = vs;
     o->max_items = max_items;
     o->items.dev = o->device;
+    o->items.stream = s;
     DevBuf small, recs, units, ubase, btri, scantmp, umask, hbase, unsorted, sorttmp;
-    for (DevBuf* b : {&small, &recs, &units, &ubase, &btri, &scantmp, &umask, &hbase, &unsorted, &sorttmp}) b->dev = o->device;
+    for (DevBuf* b : {&small, &recs, &units, &ubase, &btri, &scantmp, &umask, &hbase, &unsorted, &sorttmp}) { b->dev = o->device; b->stream = s; }
     Mail* mail = nullptr;
     auto cleanup = [&]() {
         for (DevBuf* b : {&small, &recs, &units, &ubase, &btri, &scantmp, &umask, &hbase, &unsorted, &sorttmp}) b->release();
@@ -1172,6 +1245,7 @@ vx_status vx_octree_aabbs(const vx_octree* o, vx_aabb* host_out, uint64_t cap, u
     DeviceGuard dg(o->device);
     DevBuf tmp;
     tmp.dev = o->device;
+    tmp.stream = o->stream;
     VX_HIP(tmp.ensure((size_t)m * sizeof(vx_aabb)));
     vx::launch_emit_morton_aabbs(o->items.as<uint64_t>(), m, o->root_min, o->vs, tmp.as<vx_aabb>(), o->stream);
     hipError_t e = hipMemcpyAsync(host_out, tmp.p, (size_t)m * sizeof(vx_aabb), hipMemcpyDeviceToHost, o->stream);
@@ -1184,8 +1258,12 @@ vx_status vx_octree_aabbs(const vx_octree* o, vx_aabb* host_out, uint64_t cap, u
 void vx_octree_free(vx_octree* o)
 {
     if (!o) return;
-    o->items.release();
-    if (o->dnodes) { DeviceGuard dg(o->device); (void)hipFree(o->dnodes); }
+    {   // vx_octree_aabbs_device is asynchronous: nothing of this octree may still be in flight when its memory goes back
+        DeviceGuard dg(o->device);
+        (void)hipStreamSynchronize(o->stream);
+        o->items.release(/*in_flight=*/false);
+        if (o->dnodes) (void)hipFree(o->dnodes);
+    }
     delete o;
 }
 

@@ -237,6 +237,10 @@ struct Lane {
     int bx, by, bz;                            // that brick
     uint32_t ob;                               // its occupied-cell bounds, loaded when the brick is posted
     uint32_t pf;                               // first word of its slices, loaded at the same time only to pull the line in
+    // Exactly-zero direction components.  Such an axis has no plane crossings, so the near-tie probes above
+    // never fire for it; instead the current cell's two neighbours along it are looked at whenever the (constant) coordinate
+    // lies within the position tolerance of the cell's planes: znear bit 2a = upper neighbour, bit 2a+1 = lower neighbour.
+    uint32_t znear;
 };
 
 // Axis selection BY VALUE.  `c ? R.x : R.y` on two struct members is an lvalue conditional: clang selects the ADDRESS and
@@ -266,6 +270,24 @@ __device__ __forceinline__ int start_cell(float o, float d, float org, float inv
     return ci > hi - 1 ? hi - 1 : ci;
 }
 
+// zero-direction axis: is the constant coordinate o within tol of the upper (bit 0) / lower (bit 1) plane of cell ci?
+__device__ __forceinline__ uint32_t zero_axis_near(float o, float org, float vs, int ci, int sh, float tol)
+{
+    const int scale = 1 << sh;
+    const float lo = org + (float)(ci * scale) * vs, hi = org + (float)((ci + 1) * scale) * vs;
+    return ((hi - o) <= tol ? 1u : 0u) | ((o - lo) <= tol ? 2u : 0u);
+}
+__device__ __forceinline__ void zero_axes_update(Lane& R, const GridParams& g, int sh)
+{
+    R.znear = 0u;
+    if (R.dx == 0.0f || R.dy == 0.0f || R.dz == 0.0f) {  // rare: skipped by the whole wave unless one of its rays is axis-parallel
+        const float tol = 2.0f * R.tolp;
+        if (R.dx == 0.0f) R.znear |= zero_axis_near(R.ox, g.org[0], g.vs, R.cx, sh, tol);
+        if (R.dy == 0.0f) R.znear |= zero_axis_near(R.oy, g.org[1], g.vs, R.cy, sh, tol) << 2;
+        if (R.dz == 0.0f) R.znear |= zero_axis_near(R.oz, g.org[2], g.vs, R.cz, sh, tol) << 4;
+    }
+}
+
 // enter level (sh = 3*level) inside walk bounds [lo, hi) at time t_lo
 __device__ __forceinline__ void enter_level(Lane& R, const GridParams& g, float inv_vs, int sh, int lox, int loy, int loz, int hix, int hiy, int hiz,
                                             float t_lo)
@@ -279,6 +301,7 @@ __device__ __forceinline__ void enter_level(Lane& R, const GridParams& g, float 
     R.t_in = t_lo;
     R.emask = 0;
     R.tau_ent = 0.0f;
+    zero_axes_update(R, g, sh);
 }
 
 // Ray r of the batch: from the ray buffer, or generated from the reference camera model (raytrace.rgen:41-47; mat*vec in glm's
@@ -355,6 +378,7 @@ __device__ __forceinline__ bool setup_ray(Lane& R, const GridParams& g, const Tr
     R.ob = 0u;
     R.pf = 0u;
     R.px = R.py = R.pz = 0;
+    R.znear = 0u;
     if (miss || !(tn <= tf) || !g.nvox) return false;
     // one virtual cell of halo around the top level: a ray sliding along the outside of a boundary face within tolerance
     // still walks next to the boundary cells and probes into them
@@ -478,7 +502,8 @@ __device__ __forceinline__ void brick_test(Lane& R, const GridParams& g, const T
             }
         }
         // cells of later slices are entered (in z) no earlier than this slice's dilated exit minus the z tolerance
-        if (R.best + 2.0f * R.tauz + R.tau_term < tsb) return;
+        // (dz == 0: every candidate slice spans the same t range, a hit in one says nothing about the others)
+        if (R.dz != 0.0f && R.best + 2.0f * R.tauz + R.tau_term < tsb) return;
     }
 }
 
@@ -500,12 +525,13 @@ __device__ __forceinline__ bool upper_step(Lane& R, const GridParams& g, const T
         const float tau_exit = sel3(ex, ey, R.taux, R.tauy, R.tauz);
         const bool start = R.emask == 0;
         const bool ez = !ex && !ey;
-        const bool fx = !ex && (R.tMx - t_o <= tau_exit + R.taux);
-        const bool fy = !ey && (R.tMy - t_o <= tau_exit + R.tauy);
-        const bool fz = !ez && (R.tMz - t_o <= tau_exit + R.tauz);
-        const bool bx = !(R.emask & 1) && (R.t_in - R.tPx <= R.taux + sel3(start, false, R.taux, 0.0f, R.tau_ent));
-        const bool by = !(R.emask & 2) && (R.t_in - R.tPy <= R.tauy + sel3(start, false, R.tauy, 0.0f, R.tau_ent));
-        const bool bz = !(R.emask & 4) && (R.t_in - R.tPz <= R.tauz + sel3(start, false, R.tauz, 0.0f, R.tau_ent));
+        const uint32_t zn = R.znear;  // zero-direction axes: neighbours by position, not by crossing time
+        const bool fx = ((zn & 1u) != 0u) || (!ex && (R.tMx - t_o <= tau_exit + R.taux));
+        const bool fy = ((zn & 4u) != 0u) || (!ey && (R.tMy - t_o <= tau_exit + R.tauy));
+        const bool fz = ((zn & 16u) != 0u) || (!ez && (R.tMz - t_o <= tau_exit + R.tauz));
+        const bool bx = ((zn & 2u) != 0u) || (!(R.emask & 1) && (R.t_in - R.tPx <= R.taux + sel3(start, false, R.taux, 0.0f, R.tau_ent)));
+        const bool by = ((zn & 8u) != 0u) || (!(R.emask & 2) && (R.t_in - R.tPy <= R.tauy + sel3(start, false, R.tauy, 0.0f, R.tau_ent)));
+        const bool bz = ((zn & 32u) != 0u) || (!(R.emask & 4) && (R.t_in - R.tPz <= R.tauz + sel3(start, false, R.tauz, 0.0f, R.tau_ent)));
         const uint32_t mx = 1u | (fx ? 2u : 0u) | (bx ? 4u : 0u);
         const uint32_t my = 1u | (fy ? 1u << 3 : 0u) | (by ? 1u << 6 : 0u);
         const uint32_t mz = 1u | (fz ? 1u << 9 : 0u) | (bz ? 1u << 18 : 0u);
@@ -604,6 +630,7 @@ __device__ __forceinline__ bool upper_step(Lane& R, const GridParams& g, const T
     R.fresh = true;
     R.todo = 0u;
     R.occ = false;
+    zero_axes_update(R, g, sh);
     return true;
 }
 
@@ -712,7 +739,7 @@ __global__ __launch_bounds__(256, 4 /*waves per SIMD: keeps the allocation at <=
     constexpr int kChunkMax = VX_T_CHUNK_MAX;  // ... and at most
     constexpr int kDonateBelow = 48;    // drain phase: donate work while at most this many lanes are busy
     constexpr float kDonateBricks = 6.0f;  // ... and only from pieces with more than this many bricks of t interval left
-    // (tools/trace_sweep.sh, tools/don_sweep.sh: the kernel is insensitive to all of them within +-5 %)
+    // (swept on the MI355X in round 1: the kernel is insensitive to all of them within +-5 %)
     const GridParams& g = P.hot.g;
     const TraceMips& M = P.hot.M;
     extern __shared__ __attribute__((aligned(16))) uint32_t m1_lds[];
@@ -1115,11 +1142,13 @@ void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* wo
     (void)hipMemsetAsync(counters, 0, sizeof(unsigned long long), s);
     const uint64_t n1 = (uint64_t)mips.d1[0] * mips.d1[1] * mips.d1[2];
     const uint32_t m1_words = (uint32_t)((n1 + 31) / 32);
-    const bool lds_m1 = (size_t)m1_words * 4 <= 40960;  // 4 workgroups x 40 KiB fit the CU's 160 KiB
+    // VOXHIP_TRACE_LDS=0 forces the global-memory mips (the path every grid above ~550^3 takes) -- used by the parity tests
+    const char* env_lds = getenv("VOXHIP_TRACE_LDS");
+    const bool lds_m1 = (size_t)m1_words * 4 <= 40960 && !(env_lds && atoi(env_lds) == 0);  // 4 workgroups x 40 KiB fit the CU's 160 KiB
     // persistent grid: 256 CUs x 4 resident 256-thread workgroups, fewer when there are not that many rays
     // Small batches (a few rays per lane) are bound by the drain of their longest rays and run faster on three waves per SIMD
     // than on four (1M rays: 0.50 ms at 768 workgroups, 0.54 ms at 1024; equal at 2M; 8M: 2.32 vs 2.12 ms).
-    static const int env_blocks = getenv("VOXHIP_TRACE_BLOCKS") ? atoi(getenv("VOXHIP_TRACE_BLOCKS")) : 0;
+    const int env_blocks = getenv("VOXHIP_TRACE_BLOCKS") ? atoi(getenv("VOXHIP_TRACE_BLOCKS")) : 0;
     const uint64_t max_blocks = env_blocks > 0 ? (uint64_t)env_blocks : (nrays <= 1500000ull ? 768ull : 1024ull);
     uint64_t nblk = (nrays + 255) / 256;
     if (nblk > max_blocks) nblk = max_blocks;
@@ -1131,7 +1160,7 @@ void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* wo
     const size_t shmem = lds_m1 ? (size_t)(m1_words + m2_words) * 4 : 0;
     // intra-wave work donation in the drain phase (default on; VOXHIP_TRACE_DONATE=0 disables).  The merge key holds the
     // voxel index in 32 bits.  spill_buf: one flag byte per ray, all zero on entry (the caller zeroes a new buffer) and on exit.
-    static const int env_donate = getenv("VOXHIP_TRACE_DONATE") ? atoi(getenv("VOXHIP_TRACE_DONATE")) : 1;
+    const int env_donate = getenv("VOXHIP_TRACE_DONATE") ? atoi(getenv("VOXHIP_TRACE_DONATE")) : 1;
     const bool donate = env_donate && spill_buf && keys && g.nvox <= 0x100000000ull && nrays < 0xFFFFFFFFull;
     uint8_t* flags = donate ? (uint8_t*)spill_buf : nullptr;
     if (donate) (void)hipMemsetAsync(keys, 0xFF, (size_t)nrays * 8, s);  // "no hit" in every ray's merge key

@@ -19,6 +19,9 @@ STATUS_NAMES = {0: "VX_OK", 1: "VX_ERR_INVALID_ARG", 2: "VX_ERR_PATH", 3: "VX_ER
 AABB = np.dtype([("mn", np.float32, 3), ("mx", np.float32, 3)])
 NODE = np.dtype([("children", np.uint32, 8), ("start", np.uint32), ("count", np.uint32)])
 HIT = np.dtype([("ray", np.uint32), ("prim", np.uint32), ("t", np.float32)])
+MATERIAL = np.dtype([("ambient", np.float32, 3), ("diffuse", np.float32, 3), ("specular", np.float32, 3), ("transmittance", np.float32, 3),
+                     ("emission", np.float32, 3), ("shininess", np.float32), ("ior", np.float32), ("dissolve", np.float32),
+                     ("illum", np.int32), ("texture_id", np.int32)])
 
 
 class GridDesc(C.Structure):
@@ -50,7 +53,8 @@ class VxError(RuntimeError):
 SYMBOLS = [
     "vx_last_error", "vx_status_string", "vx_device_count", "vx_set_device", "vx_release_cached_memory",
     "vx_mesh_load_obj", "vx_mesh_from_arrays", "vx_mesh_from_device", "vx_mesh_num_vertices", "vx_mesh_num_triangles",
-    "vx_mesh_host_vertices", "vx_mesh_host_indices", "vx_mesh_free",
+    "vx_mesh_host_vertices", "vx_mesh_host_indices", "vx_mesh_num_materials", "vx_mesh_materials", "vx_mesh_host_material_ids",
+    "vx_mesh_set_materials", "vx_mesh_free",
     "vx_voxelize", "vx_voxelize_into",
     "vx_grid_create", "vx_grid_describe", "vx_grid_set_voxel", "vx_grid_test_voxel", "vx_grid_coords", "vx_grid_bytes",
     "vx_grid_bitmask", "vx_grid_bitmask_device", "vx_grid_bitmask_device_mut", "vx_grid_refresh", "vx_grid_aabbs",
@@ -115,6 +119,12 @@ def lib():
     L.vx_mesh_host_vertices.restype = vp
     L.vx_mesh_host_indices.argtypes = [vp]
     L.vx_mesh_host_indices.restype = vp
+    L.vx_mesh_num_materials.argtypes = [vp]
+    L.vx_mesh_num_materials.restype = C.c_size_t
+    L.vx_mesh_materials.argtypes = [vp, vp, C.c_size_t]
+    L.vx_mesh_host_material_ids.argtypes = [vp]
+    L.vx_mesh_host_material_ids.restype = vp
+    L.vx_mesh_set_materials.argtypes = [vp, vp, C.c_size_t, vp]
     L.vx_mesh_free.argtypes = [vp]
     L.vx_mesh_free.restype = None
     L.vx_voxelize.argtypes = [vp, C.c_float, C.c_int, C.POINTER(VoxelizeOpts), C.POINTER(vp)]
@@ -258,6 +268,22 @@ class Mesh:
         v = np.ctypeslib.as_array(C.cast(vp_, C.POINTER(C.c_float)), shape=(nv * 3,)).reshape(nv, 3).copy() if nv else np.zeros((0, 3), np.float32)
         t = np.ctypeslib.as_array(C.cast(ip_, C.POINTER(C.c_int32)), shape=(nt * 3,)).reshape(nt, 3).copy() if nt else np.zeros((0, 3), np.int32)
         return v, t
+
+    def materials(self):
+        """(records MATERIAL[n], per-triangle ids int32[T] or None): tinyobj's GetMaterials() / mesh.material_ids."""
+        n = lib().vx_mesh_num_materials(self.h)
+        recs = np.zeros(n, dtype=MATERIAL)
+        if n:
+            _check(lib().vx_mesh_materials(self.h, recs.ctypes.data, n))
+        ip_ = lib().vx_mesh_host_material_ids(self.h)
+        nt = self.num_triangles
+        ids = np.ctypeslib.as_array(C.cast(ip_, C.POINTER(C.c_int32)), shape=(nt,)).copy() if (ip_ and nt) else None
+        return recs, ids
+
+    def set_materials(self, records, tri_ids):
+        r = np.ascontiguousarray(records, dtype=MATERIAL)
+        ids = None if tri_ids is None else np.ascontiguousarray(tri_ids, dtype=np.int32)
+        _check(lib().vx_mesh_set_materials(self.h, r.ctypes.data if r.size else None, r.size, ids.ctypes.data if ids is not None else None))
 
     def free(self):
         if self.h:
