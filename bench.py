@@ -2,7 +2,8 @@
 """bench.py -- one "step" = one pass of the hot path over one batch of synthetic input, inputs resident in HBM:
 
     VoxelGridVec-flavoured buildVoxelGrid (bbox, grid dims, SAT voxelization into the occupancy bitmask AND the
-    ordered-with-duplicates AABB list)  ->  VoxelGridBool::getAabbs (ascending AABB list)  ->  first-hit trace of R rays.
+    ordered-with-duplicates AABB list)  ->  getAabbs (for the Vec flavour the list the build produced: a device copy;
+    `--flavour bool` runs VoxelGridBool::getAabbs = scan + k_emit_bool instead)  ->  first-hit trace of R rays.
 
 Workload (N=1): BASELINE.json configs[2] -- the Sponza-like `atrium262k` scene (261 496 triangles, synthetic: the reference
 ships no meshes) at voxelsize 32/512 = exactly 512^3 cells, VecEncoding path, with configs[1]'s ray recipe (1M random rays,
@@ -10,17 +11,24 @@ tmin 0.001, tmax 1e4).  The north-star target (>=10 Mrays/s on a 512^3 grid) is 
 
 N>1 (one process per GPU, torch.distributed / RCCL): every rank voxelizes only its word-aligned shard of the SAME grid,
 one all-gather of the shards over xGMI rebuilds the full bitmask on every rank (word-disjoint shards: all-gather == OR),
-then every rank traces its own R rays (weak scaling in rays).  value = all ranks' rays / max-over-ranks step time.
+then every rank traces its own R rays (weak scaling in rays).  value = all ranks' rays / max-over-ranks step time.  The
+grid stays the N=1 grid so that the per-N values form one curve; BASELINE configs[3] (the same scene at 1024^3, sharded) is
+measured beside it, untimed for `value`, as `c4_1024` (`--grid 1024` makes it the timed workload instead).
+Started WITHOUT a launcher (`--gpus N`, no WORLD_SIZE in the environment) the script starts its N ranks itself -- child
+processes created before this process touches the GPU -- and relays rank 0's line.
 
 Timing: W untimed warm-up steps, an untimed survey pass (HIP events around EVERY kernel launch -> `kernels_survey_pass`, the
 dominant kernel), then EXACTLY K timed steps between barrier + synchronize on both sides; inside the timed region only the
-dominant kernel is bracketed by events (-> `roofline`), and the stage events are read after the region.
+dominant kernel is bracketed by events (-> `roofline`), and the stage events are read after the region.  After the timed
+region (untimed) a sample of the traced rays is compared with the oracle's brute force -> `verified`.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,7 +42,9 @@ for _p in (ROOT, PKG):
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+VALU_ISSUE_PEAK = 1.2288e12  # wave64 VALU instructions/s: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction
+PROFILE_TAGS = ("r2", "r1")  # profiles/<tag>_traffic.json / _issue.json, newest first
 
 
 def parse():
@@ -46,13 +56,50 @@ def parse():
     ap.add_argument("--grid", type=int, default=512)
     ap.add_argument("--rays", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--cpu-ray-sample", type=int, default=1500)
+    ap.add_argument("--cpu-runs", type=int, default=5, help="repetitions of the CPU voxelizer timings (mean and min are reported)")
+    ap.add_argument("--verify-rays", type=int, default=1000)
     ap.add_argument("--big-rays", type=int, default=8_000_000, help="extra untimed-for-`value` measurement: trace throughput on a large batch (0 = skip)")
+    ap.add_argument("--c4-grid", type=int, default=1024, help="N>1: also measure the sharded build + exchange at this resolution (0 = skip)")
     ap.add_argument("--flavour", default="vec", choices=["vec", "bool"],
                     help="vec: VoxelGridVec build (BASELINE configs[2]); bool: VoxelGridBool build + K4 getAabbs (the app's default path)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; the driver's multi-GPU runs) or gloo (rehearsal)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses device 0")
     return ap.parse_args()
+
+
+def spawn_ranks(a):
+    """`--gpus N` without a launcher: start N ranks as fresh child processes (this process has not touched the GPU: no HIP
+    call, no torch.cuda.is_available()) and relay rank 0's JSON line.  Never exec: a GPU-initialised process must not be
+    replaced, and this one stays around to collect the children."""
+    if not a.single_device:
+        ndev = torch.cuda.device_count()  # counting devices does not initialise the GPU on this image
+        if ndev < a.gpus:
+            raise SystemExit("--gpus %d but only %d device(s) visible (use --single-device --dist-backend gloo to rehearse)" % (a.gpus, ndev))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    line = None
+    for ln in (out or "").splitlines():
+        if ln.startswith("{"):
+            line = ln
+        else:
+            sys.stderr.write(ln + "\n")
+    if any(rcs) or line is None:
+        raise SystemExit("rank exit codes %s, no JSON line from rank 0" % rcs if line is None else "rank exit codes %s" % rcs)
+    if json.loads(line).get("n_gpus") != a.gpus:
+        raise SystemExit("asked for %d ranks, the job reports %s" % (a.gpus, json.loads(line).get("n_gpus")))
+    print(line)
 
 
 class DevView:
@@ -62,16 +109,39 @@ class DevView:
         self.__cuda_array_interface__ = {"shape": (nwords,), "typestr": "<i4", "data": (ptr, False), "version": 3, "strides": None}
 
 
+def reference_sat_calls(verts, tris, vs, org, dim):
+    """Number of triBoxOverlap calls the reference's loop nest makes (VoxelBuilder.hpp:175-195): the candidate volume of every
+    triangle, start = max(0, int((triMin - gridMin) / vs)), end = min(dim, int((triMax - gridMin) / vs) + 2), in float32."""
+    p = verts[tris]                                   # (T, 3 vertices, 3 axes)
+    tmn, tmx = p.min(axis=1), p.max(axis=1)
+    org = org.astype(np.float32)
+    s = np.maximum(((tmn - org) / np.float32(vs)).astype(np.int64), 0)
+    e = np.minimum(((tmx - org) / np.float32(vs)).astype(np.int64) + 2, np.array(dim, np.int64))
+    return int(np.prod(np.maximum(e - s, 0), axis=1).sum())
+
+
+def load_profile_json(suffix):
+    for tag in PROFILE_TAGS:
+        try:
+            with open(os.path.join(ROOT, "profiles", "%s_%s.json" % (tag, suffix))) as fh:
+                return tag, json.load(fh)
+        except (OSError, ValueError):
+            continue
+    return None, None
+
+
 def main():
     a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(a)
     import voxhip
     import vx_scenes
     import vx_dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world and world > 1:
+    if a.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
@@ -87,6 +157,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(a.dist_backend, rank=rank, world_size=world)
+        if dist.get_world_size() != a.gpus:
+            raise SystemExit("process group has %d ranks, --gpus %d" % (dist.get_world_size(), a.gpus))
     dev = torch.device("cuda", local)
 
     # ---- synthetic inputs, resident in HBM before anything is timed
@@ -111,7 +183,7 @@ def main():
     # the Bool flavour one per occupied voxel -- for N > 1 the unsharded count, the timed loop rebuilds the mask from shards)
     cap = max(desc["set_calls"] if kind == voxhip.GRID_VEC else desc["occupied"], 1)
     d_aabbs = torch.empty(cap * 6, dtype=torch.float32, device=dev)
-    gathered = torch.empty(chunk * world, dtype=torch.int32, device=dev) if world > 1 else None
+    exch = vx_dist.Exchange(nwords, rank, world, dev, dist) if world > 1 else None
 
     # stage boundaries: five events per timed step, all read AFTER the timed region (reading them per step needs a device
     # synchronize per step, i.e. ~50 us of idle GPU per 1 ms step that is not part of the workload)
@@ -130,7 +202,7 @@ def main():
             ev[1].record()
         if world > 1:
             mask = torch.as_tensor(DevView(grid.bitmask_device_ptr(mutable=True), nwords), device=dev)
-            vx_dist.exchange_bitmask(mask, gathered, wb, we, chunk, dist)
+            exch.run(mask)
         if timed:
             ev[2].record()
         n = grid.aabbs_device(d_aabbs.data_ptr(), cap)
@@ -190,6 +262,43 @@ def main():
     value = total_rays * a.steps / dt / 1e6
 
     hits = int((d_t > 0).sum().item())
+    h_t = d_t.cpu().numpy()
+    h_prim = d_prim.cpu().numpy().view(np.uint32)
+
+    # ---- BASELINE configs[3] beside the timed workload (N > 1): sharded build + exchange of the same scene at 1024^3
+    c4 = None
+    if world > 1 and a.c4_grid and a.c4_grid != a.grid:
+        vs4 = np.float32(ext / a.c4_grid)
+        g4 = voxhip.Grid.voxelize(mesh, vs4, voxhip.GRID_BOOL)
+        d4 = g4.describe()
+        nw4 = d4["num_words"]
+        b4, e4, _ = voxhip.shard_words(nw4, rank, world)
+        ex4 = vx_dist.Exchange(nw4, rank, world, dev, dist)
+        ev4 = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        acc = np.zeros(2)
+        reps = 5
+        for k in range(reps + 1):
+            barrier()
+            ev4[0].record()
+            g4.revoxelize(mesh, vs4, words=(b4, e4))
+            ev4[1].record()
+            ex4.run(torch.as_tensor(DevView(g4.bitmask_device_ptr(mutable=True), nw4), device=dev))
+            ev4[2].record()
+            torch.cuda.synchronize()
+            if k:
+                acc += (ev4[0].elapsed_time(ev4[1]), ev4[1].elapsed_time(ev4[2]))
+        acc /= reps
+        tt = torch.tensor(acc, dtype=torch.float64, device=dev if a.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        acc = tt.cpu().numpy()
+        g4.refresh()
+        occ4 = g4.describe()["occupied"]
+        n4 = int(np.prod(d4["dim"]))
+        c4 = {"workload": "%s @ %d^3, %d word shards + all-gather" % (a.scene, a.c4_grid, world), "grid_dim": list(d4["dim"]),
+              "voxelize_ms": round(float(acc[0]), 4), "exchange_ms": round(float(acc[1]), 4), "exchange_bytes_per_rank": int(ex4.bytes_per_rank),
+              "exchange_algo": ex4.algo, "mvoxels_per_s": round(n4 / ((acc[0] + acc[1]) * 1e-3) / 1e6, 1), "occupied_voxels": int(occ4)}
+        del g4
+
     # throughput regime of the ray kernel: at 1M rays the persistent kernel holds only 4 rays per lane and is dominated by its
     # ramp/tail; a large batch shows the steady-state rate (reported separately, never as `value`)
     big = None
@@ -210,6 +319,7 @@ def main():
         del d_rb, d_tb, d_pb
     if rank != 0:
         if dist is not None:
+            dist.barrier()
             dist.destroy_process_group()
         return
 
@@ -222,84 +332,134 @@ def main():
         "k_emit_bool": 4 * ((N + 31) // 32) + 24 * gd["occupied"],
         "k_emit_units": 36 * T + 24 * gd["set_calls"],
     }
-    roof = None
+    roof = roof_issue = None
     if dom is not None:
         ms, n = kern[dom]
         avg_ms = ms / max(n, 1)
         ab = alg_bytes.get(dom)
         ach = (ab / (avg_ms * 1e-3) / 1e9) if ab else None
+        same_workload = a.scene == "atrium262k" and R == 1_000_000 and a.grid == 512 and world == 1
         traffic = None
-        try:  # HBM bytes per launch from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this workload (profiles/, committed)
-            with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as fh:
-                tj = json.load(fh)
-            if tj.get("workload") == a.scene and tj.get("rays") == R and tj.get("grid") == a.grid:
-                traffic = tj["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
-        except (OSError, ValueError):
-            pass
-        issue = None
-        try:  # instruction-issue view from the SQ_* PMC passes (profiles/, committed): the kernel is not HBM bound
-            with open(os.path.join(ROOT, "profiles", "r1_issue.json")) as fh:
-                issue = json.load(fh)["kernels"].get(dom)
-        except (OSError, ValueError, KeyError):
-            pass
-        roof = {"bound": "hbm", "kernel": dom, "avg_launch_ms": round(avg_ms, 5), "launches": int(n),
+        ttag, tj = load_profile_json("traffic")
+        if tj and same_workload:  # HBM bytes per launch from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this workload (profiles/, committed)
+            traffic = tj["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
+        itag, ij = load_profile_json("issue")
+        issue = ij["kernels"].get(dom) if (ij and same_workload) else None
+        limiter = "hbm"
+        if issue:
+            # what the PMC passes say bounds the kernel: instruction issue / latency when the algorithmic-bytes fraction is tiny
+            wps = issue["valu_wave_insts"] / (avg_ms * 1e-3)
+            roof_issue = {"bound": "valu_issue", "kernel": dom, "achieved": round(wps, 1), "peak": VALU_ISSUE_PEAK, "unit": "wave64 VALU instr/s",
+                          "frac": round(wps / VALU_ISSUE_PEAK, 4), "lane_utilisation": issue.get("lane_utilisation"),
+                          "wait_share_of_wave_cycles": issue.get("wait_share_of_wave_cycles"), "valu_wave_insts_per_launch": issue["valu_wave_insts"],
+                          "source": "profiles/%s_issue.json (rocprofv3 SQ_* passes of this command) / live avg launch time" % itag}
+            if ach is not None and ach / HBM_PEAK_GBS < 0.05:
+                limiter = "valu_issue+latency"
+        roof = {"bound": "hbm", "limiter": limiter, "kernel": dom, "avg_launch_ms": round(avg_ms, 5), "launches": int(n),
                 "algorithmic_bytes": ab, "achieved": round(ach, 2) if ach else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 5) if ach else None, "traffic": traffic, "issue": issue,
-                "note": "VALU/latency-bound kernel: algorithmic HBM bytes are tiny next to its arithmetic; traffic from rocprofv3 PMC passes is in profiles/"}
+                "frac": round(ach / HBM_PEAK_GBS, 5) if ach else None, "traffic": traffic,
+                "note": "achieved = SURVEY 8(d) algorithmic bytes / live launch time; `limiter` is what the PMC counters say bounds the kernel "
+                        "(see roofline_issue); traffic from the rocprofv3 FETCH_SIZE/WRITE_SIZE passes in profiles/%s_traffic.json" % ttag}
     # per-kernel table: the untimed survey pass (every launch bracketed by events)
     kernels = {k: {"avg_ms": round(v[0] / max(v[1], 1), 5), "launches_per_step": round(v[1] / survey_steps, 2)} for k, v in sorted(kern_all.items())}
 
-    cpu = None
-    if not a.no_cpu_baseline:
-        cpu = cpu_baseline(verts, tris, vs, rays, a.cpu_ray_sample, R)
+    cpu, verified = None, None
+    oa = None
+    if not a.no_cpu_baseline or not a.no_verify:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle
+        ncores = os.cpu_count() or 1
+        ow, calls, gi = oracle.build_bool(verts, tris, vs, threads=min(ncores, 32))
+        oa = oracle.bool_aabbs(ow, gi, vs)
+        if not a.no_verify:
+            # untimed: a sample of the rays the timed steps traced, against the brute force over all occupied boxes
+            sel = np.random.default_rng(123).choice(R, min(a.verify_rays, R), replace=False)
+            ot, op = oracle.trace_brute(oa, rays[sel], threads=ncores)
+            words = grid.bitmask()
+            verified = bool(np.array_equal(h_t[sel], ot) and np.array_equal(h_prim[sel], op) and np.array_equal(words, ow) and int(nocc) == (gd["set_calls"] if kind == voxhip.GRID_VEC else len(oa)))
+        if not a.no_cpu_baseline:
+            cpu = cpu_baseline(oracle, verts, tris, vs, rays, oa, a.cpu_ray_sample, R, a.cpu_runs)
 
+    vox_s = stage_ms[0] * 1e-3
+    sat_calls = reference_sat_calls(verts, tris, vs, desc["bbox_min"], desc["dim"])
     out = {
         "metric": "Mrays/s", "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic",
+        "data": "synthetic", "verified": verified,
         "config": {"workload": "%s (%d tris) @ %d^3 grid, %s + %d random rays per GPU"
                    % (a.scene, T, a.grid, "VoxelGridVec build + getAabbs" if kind == voxhip.GRID_VEC else "VoxelGridBool build + getAabbs", R), "grid_dim": list(desc["dim"]), "voxel_size": float(vs), "rays_per_gpu": R,
                    "parallelism": "1 GPU" if world == 1 else "bitmask word-shards x%d + RCCL all-gather, rays independent" % world},
-        "mvoxels_per_s": round(N / (stage_ms[0] * 1e-3) / 1e6, 1),
+        "mvoxels_per_s": round(N / vox_s / 1e6, 1),
+        "occupied_voxels_per_s": round(gd["occupied"] / vox_s, 1), "set_voxel_calls_per_s": round(gd["set_calls"] / vox_s, 1),
+        "sat_tests_per_s": round(sat_calls / vox_s, 1), "sat_tests_reference_loop": sat_calls,
         "mrays_per_s_trace_stage": round(R * world / (stage_ms[3] * 1e-3) / 1e6, 1),
         "stages_ms": {"voxelize": round(float(stage_ms[0]), 4), "exchange": round(float(stage_ms[1]), 4),
                       "get_aabbs": round(float(stage_ms[2]), 4), "trace": round(float(stage_ms[3]), 4)},
-        "occupied_voxels": int(nocc), "set_calls": gd["set_calls"], "ray_hits_rank0": hits,
+        "occupied_voxels": gd["occupied"], "aabbs_returned": int(nocc), "set_calls": gd["set_calls"], "ray_hits_rank0": hits,
         "trace_large_batch": big,
         "kernel_rooflines": {k: {"achieved_GBps": round(alg_bytes[k] / (kern_all[k][0] / max(kern_all[k][1], 1) * 1e-3) / 1e9, 1),
                                  "frac_of_8TBps": round(alg_bytes[k] / (kern_all[k][0] / max(kern_all[k][1], 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
                              for k in alg_bytes if k in kern_all},
-        "kernels_survey_pass": kernels, "roofline": roof, "cpu_baseline": cpu,
+        "kernels_survey_pass": kernels, "roofline": roof, "roofline_issue": roof_issue, "cpu_baseline": cpu,
     }
+    if world > 1:
+        out["rccl_world"] = dist.get_world_size()
+        out["exchange"] = {"algo": exch.algo, "bytes_per_rank": int(exch.bytes_per_rank), "ms": round(float(stage_ms[1]), 4),
+                           "GBps_per_rank": round(exch.bytes_per_rank * (world - 1) / max(stage_ms[1], 1e-9) / 1e6, 2)}
+        out["c4_1024"] = c4
     print(json.dumps(out))
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(verts, tris, vs, rays, nsample, R):
-    """The CPU restatement of the reference path (oracle/, kind "port") timed on this host: serial driver = the
-    reference's default (inParaell=false, hello_vulkan.cpp:677), getAabbs, and a brute-force first-hit over a bounded ray
-    sample (the reference has no CPU ray path; the brute force is the definition of the result).  Bounded to ~20 s."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle
+def cpu_baseline(oracle, verts, tris, vs, rays, oa, nsample, R, runs):
+    """The CPU restatement of the reference path (oracle/, kind "port") timed on this host with the Benchmaker method
+    (hello_vulkan.h:181-240: N runs, mean; min beside it): the serial driver = the reference's default (inParaell=false,
+    hello_vulkan.cpp:677), the threaded driver (VoxelBuilder.hpp:424-541) on every core, getAabbs -- and, because the
+    reference has NO CPU ray path (its rays run in the Vulkan RT pipeline), two labelled stand-ins for the ray stage: the
+    brute force that defines the result, and the oracle's grid-walking tracer when it is built."""
     ncores = os.cpu_count() or 1
+
+    def timed(fn, n):
+        ts = []
+        res = None
+        for _ in range(n):
+            t0 = time.perf_counter()
+            res = fn()
+            ts.append(time.perf_counter() - t0)
+        return res, float(np.mean(ts)), float(np.min(ts))
+
+    (w, calls, gi), ser_mean, ser_min = timed(lambda: oracle.build_bool(verts, tris, vs), runs)
+    _, thr_mean, thr_min = timed(lambda: oracle.build_bool(verts, tris, vs, threads=ncores), runs)
+    _, vec_mean, vec_min = timed(lambda: oracle.build_vec(verts, tris, vs, cap=calls), max(2, runs // 2))
+    _, aabb_mean, aabb_min = timed(lambda: oracle.bool_aabbs(w, gi, vs), runs)
     t0 = time.perf_counter()
-    w, calls, gi = oracle.build_bool(verts, tris, vs)
-    t1 = time.perf_counter()
-    aabbs = oracle.bool_aabbs(w, gi, vs)
-    t2 = time.perf_counter()
-    vec = oracle.build_vec(verts, tris, vs, cap=calls)
-    t3 = time.perf_counter()
-    oracle.trace_brute(aabbs, rays[:nsample], threads=ncores)
-    t4 = time.perf_counter()
-    build_s, aabb_s, vec_s, trace_s = t1 - t0, t2 - t1, t3 - t2, (t4 - t3)
-    step_s = vec_s + aabb_s + trace_s * (R / nsample)
+    oracle.trace_brute(oa, rays[:nsample], threads=ncores)
+    brute_s = time.perf_counter() - t0
     N = gi["dim"][0] * gi["dim"][1] * gi["dim"][2]
-    return {"value": round(R / step_s / 1e6, 6), "unit": "Mrays/s", "cores": ncores, "kind": "port",
-            "sample": "full voxelize (serial driver, 1 thread: VoxelGridVec build %.3f s; VoxelGridBool build %.3f s) + getAabbs %.3f s on "
-                      "the full %d^3 scene; brute-force first-hit of %d of the %d rays on %d threads (%.3f s), extrapolated linearly"
-                      % (vec_s, build_s, aabb_s, gi["dim"][0], nsample, R, ncores, trace_s),
-            "voxelize_mvoxels_per_s_1thread": round(N / build_s / 1e6, 2), "brute_force_mrays_per_s": round(nsample / trace_s / 1e6, 6)}
+    walk = None
+    if hasattr(oracle, "trace_walk"):
+        nw = min(R, 200_000)
+        t0 = time.perf_counter()
+        oracle.trace_walk(w, gi, vs, rays[:nw], threads=ncores)
+        walk_s = time.perf_counter() - t0
+        walk = {"rays": nw, "seconds": round(walk_s, 4), "mrays_per_s": round(nw / walk_s / 1e6, 4), "threads": ncores}
+    ray_s = (walk["seconds"] * R / walk["rays"]) if walk else brute_s * (R / nsample)
+    step_s = vec_mean + aabb_mean + ray_s
+    return {"value": round(R / step_s / 1e6, 6), "unit": "Mrays/s", "cores": ncores, "kind": "port", "runs": runs,
+            "sample": "voxelizer on the full %d^3 scene, %d runs each: serial driver (1 thread) VoxelGridBool %.3f s mean / %.3f s min, "
+                      "VoxelGridVec %.3f / %.3f s; threaded driver (%d threads) %.3f / %.3f s; getAabbs %.4f / %.4f s.  Rays (the "
+                      "reference has no CPU ray path): %s; `value` = rays / (VoxelGridVec build + getAabbs + ray stage)"
+                      % (gi["dim"][0], runs, ser_mean, ser_min, vec_mean, vec_min, ncores, thr_mean, thr_min, aabb_mean, aabb_min,
+                         ("grid-walking CPU tracer on %d of the %d rays, %d threads, %.3f s, scaled linearly" % (walk["rays"], R, ncores, walk["seconds"]))
+                         if walk else ("brute force over all boxes on %d of the %d rays, %d threads, %.3f s, scaled linearly" % (nsample, R, ncores, brute_s))),
+            "voxelize_serial_s": {"mean": round(ser_mean, 4), "min": round(ser_min, 4)},
+            "voxelize_threaded_s": {"mean": round(thr_mean, 4), "min": round(thr_min, 4), "threads": ncores},
+            "voxelize_vec_serial_s": {"mean": round(vec_mean, 4), "min": round(vec_min, 4)},
+            "get_aabbs_s": {"mean": round(aabb_mean, 5), "min": round(aabb_min, 5)},
+            "voxelize_mvoxels_per_s_1thread": round(N / ser_mean / 1e6, 2), "voxelize_mvoxels_per_s_threaded": round(N / thr_mean / 1e6, 2),
+            "brute_force_mrays_per_s": round(nsample / brute_s / 1e6, 6), "cpu_ray_walk": walk}
 
 
 if __name__ == "__main__":

@@ -68,8 +68,11 @@ def lib():
         L.vxo_octree_free.argtypes = [C.c_void_p]
         L.vxo_hit_aabb.argtypes = [C.c_void_p, fp, fp]
         L.vxo_hit_aabb.restype = C.c_float
+        L.vxo_hit_aabb_fast.argtypes = [C.c_void_p, fp, fp]
+        L.vxo_hit_aabb_fast.restype = C.c_float
         L.vxo_trace_brute.argtypes = [C.c_void_p, C.c_uint64, fp, C.c_uint64, C.c_float, C.c_float, C.c_int, fp, u32p]
         L.vxo_primary_rays.argtypes = [fp, fp, C.c_uint32, C.c_uint32, fp]
+        L.vxo_primary_rays_pixels.argtypes = [fp, fp, C.c_uint32, C.c_uint32, u64p, C.c_uint64, fp]
         L.vxo_trace_any_brute.argtypes = [C.c_void_p, C.c_uint64, fp, C.c_uint64, C.c_float, C.c_float, fp, C.POINTER(C.c_uint8)]
         L.vxo_cube_normal.argtypes = [C.c_void_p, fp, fp, C.c_float, fp]
         _lib = L
@@ -202,6 +205,15 @@ def hit_aabb(box, o, d):
     return float(lib().vxo_hit_aabb(b.ctypes.data, _f(o), _f(d)))
 
 
+def hit_aabb_fast(box, o, d):
+    """The brute-force loop's inlined form of hit_aabb (must equal hit_aabb bit for bit)."""
+    b = np.zeros(1, dtype=AABB)
+    b[0] = box
+    o = np.ascontiguousarray(o, dtype=np.float32)
+    d = np.ascontiguousarray(d, dtype=np.float32)
+    return float(lib().vxo_hit_aabb_fast(b.ctypes.data, _f(o), _f(d)))
+
+
 def trace_brute(aabbs, rays, tmin=0.001, tmax=10000.0, threads=None):
     """First hit per ray by brute force over the AABB list -> (t float32[R] (-1 = miss), prim uint32[R])."""
     a = np.ascontiguousarray(aabbs, dtype=AABB)
@@ -219,6 +231,16 @@ def primary_rays(view_inv, proj_inv, W, H):
     pi = np.ascontiguousarray(proj_inv, dtype=np.float32).reshape(16)
     rays = np.zeros((H * W, 6), dtype=np.float32)
     lib().vxo_primary_rays(_f(vi), _f(pi), W, H, _f(rays))
+    return rays
+
+
+def primary_rays_pixels(view_inv, proj_inv, W, H, pixels):
+    """Primary rays of selected pixels (index py*W + px) of a W x H image."""
+    vi = np.ascontiguousarray(view_inv, dtype=np.float32).reshape(16)
+    pi = np.ascontiguousarray(proj_inv, dtype=np.float32).reshape(16)
+    px = np.ascontiguousarray(pixels, dtype=np.uint64)
+    rays = np.zeros((px.size, 6), dtype=np.float32)
+    lib().vxo_primary_rays_pixels(_f(vi), _f(pi), W, H, _u64(px), px.size, _f(rays))
     return rays
 
 

@@ -648,15 +648,35 @@ float vxo_hit_aabb(const vxo_aabb* b, const float o[3], const float d[3])
  * rays = 6 floats each (origin xyz, direction xyz).
  */
 typedef struct { const vxo_aabb* boxes; uint64_t n; const float* rays; uint64_t r0, r1; float tmin, tmax; float* t; uint32_t* prim; } trace_arg;
+/* fminf / fmaxf written out (the operand that is not a NaN; the smaller / larger otherwise) so that the brute-force loop does
+ * not call into libm 12 times per box; tests/test_oracle.py checks hit_aabb_inv == vxo_hit_aabb, NaN cases included. */
+static inline float fmin_(float a, float b) { return (a < b || b != b) ? a : b; }
+static inline float fmax_(float a, float b) { return (a > b || b != b) ? a : b; }
+/* vxo_hit_aabb with invDir = 1.0 / dir (rint:48) computed once per ray instead of once per box: the same floats */
+static inline float hit_aabb_inv(const vxo_aabb* b, const float o[3], const float inv[3])
+{
+    const float bx = inv[0] * (b->mn[0] - o[0]), tx = inv[0] * (b->mx[0] - o[0]);
+    const float by = inv[1] * (b->mn[1] - o[1]), ty = inv[1] * (b->mx[1] - o[1]);
+    const float bz = inv[2] * (b->mn[2] - o[2]), tz = inv[2] * (b->mx[2] - o[2]);
+    const float t0 = fmax_(fmin_(tx, bx), fmax_(fmin_(ty, by), fmin_(tz, bz)));
+    const float t1 = fmin_(fmax_(tx, bx), fmin_(fmax_(ty, by), fmax_(tz, bz)));
+    return t1 > fmax_(t0, 0.0f) ? t0 : -1.0f;
+}
+float vxo_hit_aabb_fast(const vxo_aabb* b, const float o[3], const float d[3])  /* exported for the equivalence test only */
+{
+    const float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
+    return hit_aabb_inv(b, o, inv);
+}
 static void* trace_main(void* p)
 {
     trace_arg* a = (trace_arg*)p;
     for (uint64_t r = a->r0; r < a->r1; ++r) {
         const float* o = a->rays + 6 * r;
         const float* d = o + 3;
+        const float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
         float best = a->tmax; uint32_t bp = 0xFFFFFFFFu; int found = 0;
         for (uint64_t i = 0; i < a->n; ++i) {
-            const float t = vxo_hit_aabb(&a->boxes[i], o, d);
+            const float t = hit_aabb_inv(&a->boxes[i], o, inv);
             if (t > 0.0f && t >= a->tmin && (found ? t < best : t <= best)) { best = t; bp = (uint32_t)i; found = 1; }
         }
         a->t[r] = found ? best : -1.0f;
@@ -687,23 +707,29 @@ void vxo_trace_brute(const vxo_aabb* boxes, uint64_t n, const float* rays, uint6
 /* a23 primary-ray model               shaders/raytrace.rgen:41-47 with the matrices passed in (column-major,
  * glm layout).  Writes 6 floats per pixel, row-major pixels.  normalize = v * inversesqrt(dot(v,v)) in glm;
  * restated with 1/sqrtf. */
+static void primary_ray_pixel(const float viewInv[16], const float projInv[16], uint32_t W, uint32_t H, uint32_t px, uint32_t py, float* out)
+{
+    const float u = ((float)px + 0.5f) / (float)W, v = ((float)py + 0.5f) / (float)H;
+    const float dx = u * 2.0f - 1.0f, dy = v * 2.0f - 1.0f;
+    float tgt[4];
+    /* mat4*vec4 in glm's association: (m0*v0 + m1*v1) + (m2*v2 + m3*v3) */
+    for (int r = 0; r < 4; ++r) tgt[r] = (projInv[0 * 4 + r] * dx + projInv[1 * 4 + r] * dy) + (projInv[2 * 4 + r] * 1.0f + projInv[3 * 4 + r] * 1.0f);
+    const float il = 1.0f / sqrtf((tgt[0] * tgt[0] + tgt[1] * tgt[1]) + tgt[2] * tgt[2]);
+    const float n[3] = {tgt[0] * il, tgt[1] * il, tgt[2] * il};
+    for (int r = 0; r < 3; ++r) {
+        out[r] = viewInv[3 * 4 + r];
+        out[3 + r] = (viewInv[0 * 4 + r] * n[0] + viewInv[1 * 4 + r] * n[1]) + viewInv[2 * 4 + r] * n[2];
+    }
+}
 void vxo_primary_rays(const float viewInv[16], const float projInv[16], uint32_t W, uint32_t H, float* rays)
 {
     for (uint32_t py = 0; py < H; ++py)
-        for (uint32_t px = 0; px < W; ++px) {
-            const float u = ((float)px + 0.5f) / (float)W, v = ((float)py + 0.5f) / (float)H;
-            const float dx = u * 2.0f - 1.0f, dy = v * 2.0f - 1.0f;
-            float tgt[4];
-            /* mat4*vec4 in glm's association: (m0*v0 + m1*v1) + (m2*v2 + m3*v3) */
-            for (int r = 0; r < 4; ++r) tgt[r] = (projInv[0 * 4 + r] * dx + projInv[1 * 4 + r] * dy) + (projInv[2 * 4 + r] * 1.0f + projInv[3 * 4 + r] * 1.0f);
-            const float il = 1.0f / sqrtf((tgt[0] * tgt[0] + tgt[1] * tgt[1]) + tgt[2] * tgt[2]);
-            const float n[3] = {tgt[0] * il, tgt[1] * il, tgt[2] * il};
-            float* out = rays + 6 * ((size_t)py * W + px);
-            for (int r = 0; r < 3; ++r) {
-                out[r] = viewInv[3 * 4 + r];
-                out[3 + r] = (viewInv[0 * 4 + r] * n[0] + viewInv[1 * 4 + r] * n[1]) + viewInv[2 * 4 + r] * n[2];
-            }
-        }
+        for (uint32_t px = 0; px < W; ++px) primary_ray_pixel(viewInv, projInv, W, H, px, py, rays + 6 * ((size_t)py * W + px));
+}
+/* the same for selected pixels (index = py*W + px): images too large to materialise as a ray buffer */
+void vxo_primary_rays_pixels(const float viewInv[16], const float projInv[16], uint32_t W, uint32_t H, const uint64_t* pixels, uint64_t n, float* rays)
+{
+    for (uint64_t i = 0; i < n; ++i) primary_ray_pixel(viewInv, projInv, W, H, (uint32_t)(pixels[i] % W), (uint32_t)(pixels[i] / W), rays + 6 * i);
 }
 
 /* ---------------------------------------------------------------------------------------

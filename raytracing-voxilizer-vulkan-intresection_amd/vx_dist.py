@@ -11,6 +11,53 @@ all_gather_into_tensor.
 import torch
 
 
+class Exchange:
+    """The one-shot exchange of a sharded build, set up once per (grid size, world): rank r's words [wb, we) of `mask` are valid
+    on entry, the whole mask on exit, on every rank.
+
+    * num_words % world == 0 (1024^3 / 8, 512^3 / any power of two): IN-PLACE all-gather -- the send buffer is the rank's own
+      slice of the mask and the receive buffer the mask itself; no staging buffer, no extra device copy.
+    * otherwise: the shards are padded to `chunk` words through a persistent scratch (one copy in, one copy out).
+    """
+
+    def __init__(self, num_words, rank, world, device, dist):
+        import voxhip
+        self.n, self.rank, self.world, self.dist = num_words, rank, world, dist
+        self.wb, self.we, self.chunk = voxhip.shard_words(num_words, rank, world)
+        self.inplace = num_words % world == 0 and num_words > 0
+        self.bytes_per_rank = self.chunk * 4
+        self.backend = dist.get_backend()
+        self.algo = ("all_gather_into_tensor, in place" if self.inplace else "all_gather_into_tensor via padded scratch") + " (%s)" % self.backend
+        self.scratch = None
+        if not self.inplace:
+            dev = device if self.backend == "nccl" else "cpu"
+            self.send = torch.zeros(self.chunk, dtype=torch.int32, device=dev)
+            self.scratch = torch.empty(self.chunk * world, dtype=torch.int32, device=dev)
+
+    def run(self, mask):
+        dist = self.dist
+        if mask.is_cuda and self.backend != "nccl":
+            # rehearsal on a box without RCCL peers (gloo): stage through host memory
+            host = mask.cpu()
+            exchange_bitmask(host, torch.empty(self.chunk * self.world, dtype=mask.dtype), self.wb, self.we, self.chunk, dist)
+            mask.copy_(host.to(mask.device))
+            return mask
+        if self.inplace:
+            if self.backend == "nccl":
+                dist.all_gather_into_tensor(mask, mask[self.wb:self.we])   # RCCL over xGMI, in place: the production path
+            else:
+                _gather_fallback(mask, mask[self.wb:self.we].clone(), self.chunk, self.world, dist)
+            return mask
+        if self.we > self.wb:
+            self.send[: self.we - self.wb] = mask[self.wb:self.we]
+        if self.backend == "nccl":
+            dist.all_gather_into_tensor(self.scratch, self.send)
+        else:
+            _gather_fallback(self.scratch, self.send, self.chunk, self.world, dist)
+        mask.copy_(self.scratch[: self.n])
+        return mask
+
+
 def exchange_bitmask(mask, gathered, wb, we, chunk, dist):
     """mask: int32[num_words] on this rank, valid in [wb, we), anything elsewhere.  On return every rank holds the full
     mask.  gathered: int32[chunk*world] scratch."""
@@ -20,7 +67,7 @@ def exchange_bitmask(mask, gathered, wb, we, chunk, dist):
     if we > wb:
         send[: we - wb] = mask[wb:we]
     if mask.is_cuda and dist.get_backend() == "nccl":
-        dist.all_gather_into_tensor(gathered, send)          # RCCL over xGMI: the production path
+        dist.all_gather_into_tensor(gathered, send)          # RCCL over xGMI
         mask.copy_(gathered[:n])
     elif mask.is_cuda:
         # rehearsal on a box without RCCL peers (gloo): stage through host memory

@@ -40,7 +40,16 @@ def _worker(rank, world, port, full_path, out_dir):
     gathered = torch.empty(chunk * world, dtype=torch.int32)
     got = vx_dist.exchange_bitmask(mask.clone(), gathered, wb, we, chunk, dist)
     got2 = vx_dist.exchange_bitmask_allreduce(mask.clone(), wb, we, dist)
-    ok = bool(torch.equal(got, full)) and bool(torch.equal(got2, full))
+    # the bench's exchange object: in place when the word count divides by the world size, padded scratch otherwise
+    ex = vx_dist.Exchange(n, rank, world, "cpu", dist)
+    got3 = ex.run(mask.clone())
+    m = n - n % world    # a divisible prefix exercises the in-place branch for every world size
+    ex2 = vx_dist.Exchange(m, rank, world, "cpu", dist)
+    part = torch.full((m,), -1, dtype=torch.int32)
+    part[ex2.wb:ex2.we] = full[ex2.wb:ex2.we]
+    got4 = ex2.run(part)
+    assert ex2.inplace and ex2.bytes_per_rank == 4 * (m // world)
+    ok = bool(torch.equal(got, full)) and bool(torch.equal(got2, full)) and bool(torch.equal(got3, full)) and bool(torch.equal(got4, full[:m]))
     np.save(os.path.join(out_dir, "ok%d.npy" % rank), np.array([ok]))
     dist.destroy_process_group()
 

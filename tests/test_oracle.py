@@ -162,3 +162,28 @@ def test_empty_and_flat_inputs():
     assert not w.any() and calls == 0
     oc = oracle.octree(v, np.zeros((0, 3), np.int32), 0.25)
     assert len(oc["nodes"]) == 0 and len(oc["aabbs"]) == 0
+
+
+def test_brute_force_inner_form_equals_hit_aabb():
+    """The brute-force loop evaluates hitAabb with invDir hoisted out of the box loop and fminf/fmaxf written out; it must be
+    the same function, including the NaN products of axis-parallel rays whose origin lies exactly on a box plane
+    (inf * 0: rint:49-50) and boxes behind / around the origin."""
+    rng = np.random.default_rng(5)
+    box = np.zeros(1, dtype=oracle.AABB)[0]
+    for k in range(4000):
+        mn = rng.uniform(-2, 2, 3).astype(np.float32)
+        box["mn"], box["mx"] = mn, mn + rng.uniform(0.01, 1, 3).astype(np.float32)
+        o = rng.uniform(-3, 3, 3).astype(np.float32)
+        d = rng.normal(size=3).astype(np.float32)
+        if k % 4 == 1:
+            d[rng.integers(0, 3)] = 0.0
+        if k % 4 == 2:
+            a = rng.integers(0, 3)
+            d[a] = 0.0
+            o[a] = box["mn"][a] if k % 8 == 2 else box["mx"][a]
+        if k % 4 == 3:
+            z = rng.permutation(3)[:2]
+            d[z] = 0.0
+            o[z[0]] = box["mn"][z[0]]
+        a_, b_ = oracle.hit_aabb(box, o, d), oracle.hit_aabb_fast(box, o, d)
+        assert (a_ == b_) or (np.isnan(a_) and np.isnan(b_)), (k, a_, b_, box, o, d)
