@@ -14,8 +14,8 @@ _SO = os.path.join(_HERE, "libvxoracle.so")
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "vx_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("vx_oracle.c", "vx_walk.c", "Makefile")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "libvxoracle.so"])
     return _SO
 
@@ -75,6 +75,10 @@ def lib():
         L.vxo_primary_rays_pixels.argtypes = [fp, fp, C.c_uint32, C.c_uint32, u64p, C.c_uint64, fp]
         L.vxo_trace_any_brute.argtypes = [C.c_void_p, C.c_uint64, fp, C.c_uint64, C.c_float, C.c_float, fp, C.POINTER(C.c_uint8)]
         L.vxo_cube_normal.argtypes = [C.c_void_p, fp, fp, C.c_float, fp]
+        L.vxo_walk_create.argtypes = [u32p, u64p, C.c_float, fp]
+        L.vxo_walk_create.restype = C.c_void_p
+        L.vxo_walk_free.argtypes = [C.c_void_p]
+        L.vxo_walk_trace.argtypes = [C.c_void_p, fp, C.c_uint64, C.c_float, C.c_float, C.c_int, fp, u64p, u64p]
         _lib = L
     return _lib
 
@@ -266,3 +270,40 @@ def cube_normals(aabbs, prim, rays, t):
         lib().vxo_cube_normal(a[int(prim[i]):int(prim[i]) + 1].ctypes.data, _f(o), _f(d), np.float32(t[i]), _f(tmp))
         out[i] = tmp
     return out
+
+
+def voxel_rank(words, idx):
+    """gl_PrimitiveID of voxel index idx: its rank among the set bits of the bitmask (0xFFFFFFFF for ~0 = miss)."""
+    w = np.ascontiguousarray(words, dtype=np.uint32)
+    idx = np.asarray(idx, dtype=np.uint64)
+    pre = np.concatenate([[0], np.cumsum(np.bitwise_count(w).astype(np.uint64))])
+    hit = idx != np.uint64(0xFFFFFFFFFFFFFFFF)
+    wi = (idx[hit] >> np.uint64(5)).astype(np.int64)
+    below = w[wi] & ((np.uint32(1) << (idx[hit] & np.uint64(31)).astype(np.uint32)) - np.uint32(1))
+    out = np.full(idx.shape, 0xFFFFFFFF, dtype=np.uint32)
+    out[hit] = (pre[wi] + np.bitwise_count(below)).astype(np.uint32)
+    return out
+
+
+def trace_walk(words, gi, vs, rays, tmin=0.001, tmax=10000.0, threads=None, want_stats=False):
+    """Grid-walking CPU tracer (vx_walk.c: major-axis slab walk + the exact rint formula) -> (t, prim[, stats]).
+    Must equal trace_brute bit for bit; it is the CPU stand-in for the ray stage in bench.py's cpu_baseline."""
+    w = np.ascontiguousarray(words, dtype=np.uint32)
+    r = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+    dim = np.array(gi["dim"], dtype=np.uint64)
+    org = np.ascontiguousarray(gi["bmin"], dtype=np.float32)
+    t = np.full(r.shape[0], -1.0, dtype=np.float32)
+    idx = np.full(r.shape[0], 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)
+    stats = np.zeros(4, dtype=np.uint64)
+    if threads is None:
+        threads = os.cpu_count() or 1
+    if w.size and r.shape[0]:
+        h = lib().vxo_walk_create(_u32(w), _u64(dim), np.float32(vs), _f(org))
+        try:
+            lib().vxo_walk_trace(h, _f(r), r.shape[0], np.float32(tmin), np.float32(tmax), threads, _f(t), _u64(idx), _u64(stats))
+        finally:
+            lib().vxo_walk_free(h)
+    p = voxel_rank(w, idx) if w.size else np.full(r.shape[0], 0xFFFFFFFF, np.uint32)
+    if want_stats:
+        return t, p, dict(cell_slabs=int(stats[0]), brick_slabs=int(stats[1]), block_slabs=int(stats[2]), exact_tests=int(stats[3]))
+    return t, p

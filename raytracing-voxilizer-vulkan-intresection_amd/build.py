@@ -21,7 +21,7 @@ EXTRA = os.environ.get("VOXHIP_EXTRA_FLAGS", "").split()
 FLAGS = EXTRA + ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
          "--offload-arch=" + ARCH]
 
-SOURCES = ["vx_kernels.hip", "vx_trace.hip", "vx_octree.hip", "vx_sort.hip", "vx_api.cpp", "vx_obj.cpp", "vx_prof.cpp"]
+SOURCES = ["vx_kernels.hip", "vx_trace.hip", "vx_walk.hip", "vx_octree.hip", "vx_sort.hip", "vx_api.cpp", "vx_obj.cpp", "vx_prof.cpp"]
 HEADERS = ["vx_math.h", "vx_internal.h", os.path.join(ROOT, "include", "voxhip.h")]
 
 

@@ -415,11 +415,11 @@ vx_status ensure_coarse(vx_grid* g)
     const uint64_t nc2 = (uint64_t)g->c2dim[0] * g->c2dim[1] * g->c2dim[2];
     VX_HIP(g->cwords.ensure((size_t)((nc + 63) / 64 * 2 + 2) * 4));
     VX_HIP(g->c2words.ensure((size_t)((nc2 + 31) / 32 + 2) * 4));
-    VX_HIP(g->bricks.ensure((size_t)(nc * 8 + 8) * 8));
+    VX_HIP(g->bricks.ensure((size_t)(nc * 8 * 3 + 8) * 8));  // three orientations (x, y, z slabs); the z one is what the bounds kernel reads
     VX_HIP(g->bbounds.ensure((size_t)(nc + 8) * 4));
-    // bitmask -> brick-major slices -> per-brick bounds + level-1 mip -> level-2 mip
-    vx::launch_build_bricks(g->words.as<uint32_t>(), g->g.dim, g->cdim, g->bricks.as<unsigned long long>(), g->stream);
-    vx::launch_brick_bounds(g->bricks.as<unsigned long long>(), nc, g->bbounds.as<uint32_t>(), g->cwords.as<uint32_t>(), g->stream);
+    // bitmask -> brick-major slabs in three orientations -> per-brick bounds + level-1 mip -> level-2 mip
+    vx::launch_build_bricks3(g->words.as<uint32_t>(), g->g.dim, g->cdim, g->bricks.as<unsigned long long>(), g->stream);
+    vx::launch_brick_bounds(g->bricks.as<unsigned long long>() + 2ull * nc * 8ull, nc, g->bbounds.as<uint32_t>(), g->cwords.as<uint32_t>(), g->stream);
     vx::launch_build_mip2(g->cwords.as<uint32_t>(), g->cdim, g->c2dim, g->c2words.as<uint32_t>(), g->stream);
     g->coarse_valid = true;
     return VX_OK;
@@ -968,7 +968,8 @@ static vx_status trace_common(vx_grid* g, vx::TraceIO io)
         }
     }
     vx::TraceMips mips;
-    mips.bricks = g->bricks.as<unsigned long long>();
+    const uint64_t nbricks = (uint64_t)g->cdim[0] * g->cdim[1] * g->cdim[2];
+    mips.bricks = g->bricks.as<unsigned long long>() + 2ull * nbricks * 8ull;  // z orientation
     mips.bounds = g->bbounds.as<uint32_t>();
     mips.w0 = g->words.as<uint32_t>();
     mips.w1 = g->cwords.as<uint32_t>();
@@ -980,13 +981,16 @@ static vx_status trace_common(vx_grid* g, vx::TraceIO io)
         VX_HIP(hipStreamSynchronize(g->stream));  // the host copy lives on the caller's stack
         io.cam_dev = g->camera.as<vx::Camera>();
     }
-    VX_HIP(g->spill.ensure(vx::trace_spill_bytes(io.nrays)));
-    if (g->spill.fresh) {  // split flags: all zero between launches (the merge step clears what the trace sets)
-        VX_HIP(hipMemsetAsync(g->spill.p, 0, g->spill.cap, g->stream));
-        g->spill.fresh = false;
+    if (!vx::trace_uses_walk()) {  // scratch of the round-1 DDA's work donation
+        VX_HIP(g->spill.ensure(vx::trace_spill_bytes(io.nrays)));
+        if (g->spill.fresh) {  // split flags: all zero between launches (the merge step clears what the trace sets)
+            VX_HIP(hipMemsetAsync(g->spill.p, 0, g->spill.cap, g->stream));
+            g->spill.fresh = false;
+        }
+        VX_HIP(g->keys.ensure((size_t)io.nrays * 8 + 8));
     }
-    VX_HIP(g->keys.ensure((size_t)io.nrays * 8 + 8));
-    vx::launch_trace(g->g, mips, prefix, io, g->small.as<Small>()->trace_counters, idx_tmp, g->spill.p, g->keys.as<unsigned long long>(), g->stream);
+    vx::launch_trace(g->g, mips, g->bricks.as<unsigned long long>(), prefix, io, g->small.as<Small>()->trace_counters, idx_tmp, g->spill.p,
+                     g->keys.as<unsigned long long>(), g->stream);
     VX_HIP(hipGetLastError());
     return VX_OK;
 }

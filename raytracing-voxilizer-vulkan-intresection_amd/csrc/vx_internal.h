@@ -88,6 +88,9 @@ void launch_build_mip2(const uint32_t* m1, const uint32_t d1[3], const uint32_t 
 // K6: first hit per ray.  Three-level occupancy hierarchy: cells (bricks; w0 = the reference-layout bitmask, used for the
 // primitive rank only), 8^3 bricks (w1, dims d1), 64^3 blocks (w2, dims d2).
 void launch_build_bricks(const uint32_t* words, const uint32_t dim[3], const uint32_t bdim[3], unsigned long long* bricks, hipStream_t s);
+// the same in three orientations, one per possible major axis of a ray: bricks3[ori][brick][slab along ori], ori 0 x / 1 y / 2 z;
+// orientation 2 is launch_build_bricks' layout (bit y*8+x per z slab), orientation 0 has bit z*8+y per x slab, orientation 1 bit x*8+z
+void launch_build_bricks3(const uint32_t* words, const uint32_t dim[3], const uint32_t bdim[3], unsigned long long* bricks3, hipStream_t s);
 // also writes the level-1 mip (one bit per brick, x-fastest, (nbricks+63)/64*2 words)
 void launch_brick_bounds(const unsigned long long* bricks, uint64_t nbricks, uint32_t* bounds, uint32_t* m1, hipStream_t s);
 struct TraceMips {
@@ -115,9 +118,10 @@ struct TraceIO {
     unsigned long long* nhits = nullptr;
 };
 size_t trace_spill_bytes(uint64_t nrays);
-void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* word_prefix, const TraceIO& io,
+bool trace_uses_walk();  // slab walk (default) or the round-1 DDA (VOXHIP_TRACE_ALGO=dda): decides which scratch buffers are needed
+void launch_trace(const GridParams& g, const TraceMips& mips, const unsigned long long* bricks3, const uint32_t* word_prefix, const TraceIO& io,
                   unsigned long long* counters /*4 device words*/, unsigned long long* idx_tmp /*nrays x 8 B when ranks are wanted*/,
-                  void* spill_buf /*trace_spill_bytes(nrays)*/, unsigned long long* keys /*nrays x 8 B*/, hipStream_t s);
+                  void* spill_buf /*trace_spill_bytes(nrays), DDA only*/, unsigned long long* keys /*nrays x 8 B, DDA only*/, hipStream_t s);
 
 // single-voxel helpers
 void launch_set_bit(uint32_t* words, uint64_t idx, hipStream_t s);

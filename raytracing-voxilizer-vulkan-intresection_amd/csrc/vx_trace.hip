@@ -1054,7 +1054,7 @@ __global__ __launch_bounds__(256) void k_merge_flags(uint8_t* __restrict__ flags
 
 // Per-ray post-pass over all rays: primitive id (== gl_PrimitiveID: rank of the voxel in the ascending AABB list), the
 // cube-face normal of raytrace2.rchit:60-73, and wavefront hit compaction.
-__global__ __launch_bounds__(1024) void k_rank(float* __restrict__ t, unsigned long long* __restrict__ idx, uint64_t nrays, GridParams g,
+__global__ __launch_bounds__(1024) void k_rank(float* __restrict__ t, void* __restrict__ idx_any, int idx32, uint64_t nrays, GridParams g,
                                               const uint32_t* __restrict__ words, const uint32_t* __restrict__ word_prefix, const float* __restrict__ rays,
                                               const Camera* __restrict__ cam, uint32_t* __restrict__ prim_out, float* __restrict__ normal_out, vx_hit* __restrict__ hits,
                                               unsigned long long* nhits, uint8_t* __restrict__ split_flag, const unsigned long long* __restrict__ keys,
@@ -1066,7 +1066,10 @@ __global__ __launch_bounds__(1024) void k_rank(float* __restrict__ t, unsigned l
     uint32_t prim = 0xFFFFFFFFu;
     if (active) {
         tt = t[r];
-        unsigned long long i = idx[r];
+        unsigned long long* idx = reinterpret_cast<unsigned long long*>(idx_any);  // k_trace writes 64-bit voxel indices, k_walk 32-bit ones when they fit
+        unsigned long long i;
+        if (idx32) { const uint32_t i32 = reinterpret_cast<const uint32_t*>(idx_any)[r]; i = i32 == 0xFFFFFFFFu ? ~0ull : (unsigned long long)i32; }
+        else i = idx[r];
         if (split_flag && split_flag[r]) {  // a ray that was split by work donation: its result is the merge key (and the flag goes back to 0)
             const unsigned long long key = keys[r];
             tt = key == ~0ull ? -1.0f : __uint_as_float((uint32_t)(key >> 32));
@@ -1133,11 +1136,33 @@ __global__ __launch_bounds__(1024) void k_rank(float* __restrict__ t, unsigned l
 
 size_t trace_spill_bytes(uint64_t nrays) { return (size_t)nrays + 64; }  // one flag byte per ray: split by work donation
 
-void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* word_prefix, const TraceIO& io, unsigned long long* counters /*>= 4*/,
-                  unsigned long long* idx_tmp, void* spill_buf, unsigned long long* keys, hipStream_t s)
+void launch_walk(const GridParams& g, const TraceMips& mips, const unsigned long long* bricks3, const TraceIO& io, unsigned long long* counter,
+                 void* idx_out, bool idx32, hipStream_t s);
+
+bool trace_uses_walk()
+{
+    const char* e = getenv("VOXHIP_TRACE_ALGO");  // "dda": the round-1 three-level DDA with near-tie probes (kept for A/B); default: slab walk
+    return !(e && std::strcmp(e, "dda") == 0);
+}
+
+void launch_trace(const GridParams& g, const TraceMips& mips, const unsigned long long* bricks3, const uint32_t* word_prefix, const TraceIO& io,
+                  unsigned long long* counters /*>= 4*/, unsigned long long* idx_tmp, void* spill_buf, unsigned long long* keys, hipStream_t s)
 {
     const uint64_t nrays = io.nrays;
     if (!nrays) return;
+    if (trace_uses_walk()) {
+        const bool want_rank = (io.prim_out || io.hits || io.normal_out) && word_prefix && idx_tmp && io.t_out;
+        const bool idx32 = g.nvox < 0xFFFFFFFFull;
+        launch_walk(g, mips, bricks3, io, counters, want_rank ? (void*)idx_tmp : nullptr, idx32, s);
+        if (want_rank) {
+            if (io.hits && io.nhits) (void)hipMemsetAsync(io.nhits, 0, sizeof(unsigned long long), s);
+            const unsigned rthreads = io.hits ? 1024u : 256u;  // the hit list's compaction touches the global counter once per workgroup
+            const dim3 rgrid((unsigned)((nrays + rthreads - 1) / rthreads)), rblock(rthreads);
+            VX_KL(k_rank, rgrid, rblock, 0, s, io.t_out, (void*)idx_tmp, idx32 ? 1 : 0, nrays, g, mips.w0, word_prefix, io.rays, io.cam_dev, io.prim_out, io.normal_out,
+                  io.hits, io.nhits, (uint8_t*)nullptr, (const unsigned long long*)nullptr, io.shadowed_out);
+        }
+        return;
+    }
     // counters[0]: work counter
     (void)hipMemsetAsync(counters, 0, sizeof(unsigned long long), s);
     const uint64_t n1 = (uint64_t)mips.d1[0] * mips.d1[1] * mips.d1[2];
@@ -1188,7 +1213,7 @@ void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* wo
         if (io.hits && io.nhits) (void)hipMemsetAsync(io.nhits, 0, sizeof(unsigned long long), s);
         const unsigned rthreads = io.hits ? 1024u : 256u;  // the hit list's compaction touches the global counter once per workgroup
         const dim3 rgrid((unsigned)((nrays + rthreads - 1) / rthreads)), rblock(rthreads);
-        VX_KL(k_rank, rgrid, rblock, 0, s, io.t_out, idx_tmp, nrays, g, mips.w0, word_prefix, io.rays, io.cam_dev, io.prim_out, io.normal_out, io.hits, io.nhits,
+        VX_KL(k_rank, rgrid, rblock, 0, s, io.t_out, (void*)idx_tmp, 0, nrays, g, mips.w0, word_prefix, io.rays, io.cam_dev, io.prim_out, io.normal_out, io.hits, io.nhits,
               flags, keys, io.shadowed_out);
     } else if (donate) {
         const uint64_t nq = (nrays + 3) / 4;
