@@ -168,22 +168,41 @@ void launch_build_bricks3(const uint32_t* words, const uint32_t dim[3], const ui
 
 namespace {
 
-// everything a lane carries for the ray it is currently tracing
+// Everything a lane carries for the ray it is currently tracing, in PERMUTED axis order: w = the major axis, u and v the axes
+// after it cyclically.  hitAabb (rint:46-56) is a max of per-axis minima and a min of per-axis maxima, so evaluating it in
+// (u, v, w) order yields the same float as in (x, y, z) order; only the voxel index of a hit needs the real order.
+template <typename IdxT>
 struct WalkLane {
-    float ox, oy, oz, dx, dy, dz, ix, iy, iz;  // origin, direction, 1/direction (rint:48)
-    float ou, du, ov, dv, ow, iw;              // the same permuted: w = major axis, u, v = the axes after it cyclically
-    float orgu, orgv, orgw;                    // grid origin, permuted
-    int dimu, dimv, dimw;                      // grid dims in cells, permuted
-    int perm;                                  // w: 0 x, 1 y, 2 z
-    float tol;                                 // position tolerance
-    float tn, tf;                              // the ray inside the dilated grid box, cut to [0, tmax]
+    float ou, ov, ow;        // origin
+    float du, dv;            // direction (the major component is only needed through its reciprocal)
+    float iu, iv, iw;        // 1 / direction (rint:48)
+    float orgu, orgv, orgw;  // grid origin
+    int dimu, dimv, dimw;    // grid dims in cells
+    int perm;                // w: 0 x, 1 y, 2 z
+    float tol;               // position tolerance
+    float tn, tf;            // the ray inside the dilated grid box, cut to [0, tmax]
     float tmax;
-    float best;                                // best accepted t so far (+inf: none)
-    uint64_t best_idx;                         // voxel index of the best hit
-    int lvl, k;                                // current slab: level (2 blocks, 1 bricks, 0 cells) and index along w in cells of that level
+    float best;              // best accepted t so far (+inf: none)
+    IdxT best_idx;           // voxel index of the best hit (all ones: none)
+    int lvl, k;              // current slab: level (2 block slabs, 1 brick slabs; 0: inside a brick of brick slab k) and its index along w
+    // occupied bricks of the current brick slab's rectangle, waiting for the brick phase
+    uint32_t pend;           // bits 0..15: brick jb + j = (cu0 + (jb + j) % nu, cv0 + (jb + j) / nu) is occupied; bits 16..30: nu; bit 31: more windows
+    int jb;                  // first rectangle cell of the current 16-cell window (0 unless the rectangle has more than 16 cells)
+    uint32_t pc;             // cu0 | cv0 << 16
+    uint32_t pu, pv;         // the slab's cell rectangle: u0 | u1 << 16, v0 | v1 << 16
+    // level 0: the brick being walked -- its eight slab words (one 64-byte line) and the slabs still to look at
+    unsigned long long w0, w1, w2, w3, w4, w5, w6, w7;
+    uint32_t sm;             // bit s: slab s of the brick may hold a cell the ray touches (word & brick-level rectangle != 0)
 };
 
 __device__ __forceinline__ float sel3f(int p, float a, float b, float c) { return p == 0 ? a : (p == 1 ? b : c); }
+__device__ __forceinline__ unsigned long long sel8(int i, unsigned long long a, unsigned long long b, unsigned long long c, unsigned long long d,
+                                                   unsigned long long e, unsigned long long f, unsigned long long g, unsigned long long h)
+{
+    const unsigned long long lo = i & 2 ? (i & 1 ? d : c) : (i & 1 ? b : a);
+    const unsigned long long hi = i & 2 ? (i & 1 ? h : g) : (i & 1 ? f : e);
+    return i & 4 ? hi : lo;
+}
 __device__ __forceinline__ int sel3i(int p, int a, int b, int c) { return p == 0 ? a : (p == 1 ? b : c); }
 
 // (cu, cv, cw) in permuted order -> (x, y, z):  w=0: x=cw y=cu z=cv;  w=1: x=cv y=cw z=cu;  w=2: x=cu y=cv z=cw
@@ -222,15 +241,17 @@ __device__ __forceinline__ void load_ray_w(bool primary, uint64_t r, const float
 }
 
 // Ray set-up: major axis, tolerance, grid clip, first slab.  Returns false when the ray cannot touch the grid.
-__device__ __forceinline__ bool walk_setup(WalkLane& R, const GridParams& g, const uint32_t d2[3], float inv_vs, float tmax)
+template <typename IdxT>
+__device__ __forceinline__ bool walk_setup(WalkLane<IdxT>& R, const GridParams& g, float inv_vs, float tmax, float ox, float oy, float oz, float dx, float dy,
+                                           float dz)
 {
-    R.ix = 1.0f / R.dx; R.iy = 1.0f / R.dy; R.iz = 1.0f / R.dz;  // rint:48
-    const float ax = fabsf(R.dx), ay = fabsf(R.dy), az = fabsf(R.dz);
+    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;  // rint:48
+    const float ax = fabsf(dx), ay = fabsf(dy), az = fabsf(dz);
     const int p = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
     R.perm = p;
-    R.ow = sel3f(p, R.ox, R.oy, R.oz); R.iw = sel3f(p, R.ix, R.iy, R.iz);
-    R.ou = sel3f(p, R.oy, R.oz, R.ox); R.du = sel3f(p, R.dy, R.dz, R.dx);
-    R.ov = sel3f(p, R.oz, R.ox, R.oy); R.dv = sel3f(p, R.dz, R.dx, R.dy);
+    R.ow = sel3f(p, ox, oy, oz); R.iw = sel3f(p, ix, iy, iz);
+    R.ou = sel3f(p, oy, oz, ox); R.du = sel3f(p, dy, dz, dx); R.iu = sel3f(p, iy, iz, ix);
+    R.ov = sel3f(p, oz, ox, oy); R.dv = sel3f(p, dz, dx, dy); R.iv = sel3f(p, iz, ix, iy);
     R.orgw = sel3f(p, g.org[0], g.org[1], g.org[2]);
     R.orgu = sel3f(p, g.org[1], g.org[2], g.org[0]);
     R.orgv = sel3f(p, g.org[2], g.org[0], g.org[1]);
@@ -238,7 +259,7 @@ __device__ __forceinline__ bool walk_setup(WalkLane& R, const GridParams& g, con
     R.dimu = sel3i(p, (int)g.dim[1], (int)g.dim[2], (int)g.dim[0]);
     R.dimv = sel3i(p, (int)g.dim[2], (int)g.dim[0], (int)g.dim[1]);
     const float hx = g.org[0] + (float)g.dim[0] * g.vs, hy = g.org[1] + (float)g.dim[1] * g.vs, hz = g.org[2] + (float)g.dim[2] * g.vs;
-    float Mx = fmaxf(fmaxf(fabsf(R.ox), fabsf(R.oy)), fabsf(R.oz));
+    float Mx = fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz));
     Mx = fmaxf(Mx, fmaxf(fmaxf(fabsf(g.org[0]), fabsf(g.org[1])), fabsf(g.org[2])));
     Mx = fmaxf(Mx, fmaxf(fmaxf(fabsf(hx), fabsf(hy)), fabsf(hz)));
     // position tolerance 16 * 2^-24 * max|coordinate|: the box planes carry <= 3 roundings of grid-sized numbers, the slab
@@ -256,9 +277,9 @@ __device__ __forceinline__ bool walk_setup(WalkLane& R, const GridParams& g, con
         tn = fmaxf(tn, z ? -INFINITY : fminf(t1, t2));                                                \
         tf = fminf(tf, z ? INFINITY : fmaxf(t1, t2));                                                 \
     }
-    VX_CLIP(R.ox, R.dx, R.ix, g.org[0], hx)
-    VX_CLIP(R.oy, R.dy, R.iy, g.org[1], hy)
-    VX_CLIP(R.oz, R.dz, R.iz, g.org[2], hz)
+    VX_CLIP(ox, dx, ix, g.org[0], hx)
+    VX_CLIP(oy, dy, iy, g.org[1], hy)
+    VX_CLIP(oz, dz, iz, g.org[2], hz)
 #undef VX_CLIP
     // the clip's own rounding: widen by the time it takes to travel 2 tol along the major axis
     const float tslack = 2.0f * tol * fabsf(R.iw);
@@ -268,14 +289,19 @@ __device__ __forceinline__ bool walk_setup(WalkLane& R, const GridParams& g, con
     R.tf = tf;
     R.tmax = tmax;
     R.best = INFINITY;
-    R.best_idx = ~0ull;
+    R.best_idx = (IdxT)~(IdxT)0;
     R.lvl = 2;
     R.k = 0;
+    R.pend = 0u;
+    R.jb = 0;
+    R.pc = R.pu = R.pv = 0u;
+    R.sm = 0u;
+    R.w0 = R.w1 = R.w2 = R.w3 = R.w4 = R.w5 = R.w6 = R.w7 = 0ull;
     if (miss || !(tn <= tf)) return false;
     // first block slab: the one that holds the entry point (one cell of slack against the rounding of this estimate; slabs that
     // still lie in front of tn are skipped by the step itself)
     const bool pos = R.iw > 0.0f;
-    const float pw = sel3f(p, R.ox + tn * R.dx, R.oy + tn * R.dy, R.oz + tn * R.dz);
+    const float pw = sel3f(p, ox + tn * dx, oy + tn * dy, oz + tn * dz);
     int cw = (int)floorf((pw - R.orgw) * inv_vs) + (pos ? -1 : 1);
     cw = cw < 0 ? 0 : (cw > R.dimw - 1 ? R.dimw - 1 : cw);
     R.k = cw >> 6;
@@ -284,7 +310,12 @@ __device__ __forceinline__ bool walk_setup(WalkLane& R, const GridParams& g, con
 
 }  // namespace
 
-struct WalkParams {
+// Everything the kernel is given, as ONE by-value argument.  The walk needs the hot block in scalar registers at every step; the
+// cold block (ray source, outputs, work counter) is touched once per refill / retire.  Held as ordinary kernel arguments the
+// cold values stay live in SGPRs for the whole kernel (and the camera's 34 floats get hoisted out of the loop on top), the SGPRs
+// spill to VGPR lanes and the VGPRs to scratch; so the cold block is read from the kernarg segment where it is used, through a
+// laundered pointer that the compiler cannot hoist loads from.
+struct WalkHot {
     GridParams g;
     const unsigned long long* bricks3;  // [3 orientations][bricks][8 slabs]
     uint64_t ori_stride;                // uint64 words per orientation
@@ -295,21 +326,57 @@ struct WalkParams {
     float tmin;
     int any_hit;
     uint32_t m1_words, m2_words;
-    // touched once per refill / retire
+    uint32_t nrays;               // one launch handles at most 2^31 rays (the host loops over larger batches)
+    int donate;                   // intra-wave work donation in the drain phase (VOXHIP_TRACE_DONATE=0 switches it off)
+};
+struct WalkCold {
     const float* rays;            // null: primary rays from *cam
     const Camera* cam;
     const float* tmax_per_ray;    // null: tmax
     float tmax;
-    uint32_t idx32;               // 1: idx_out holds 32-bit voxel indices (grids of at most 2^32 - 1 voxels), 0xFFFFFFFF = miss
-    uint64_t nrays;
+    uint32_t pad;
+    uint64_t ray_base;            // index of this launch's first ray in the caller's batch (primary rays: pixel index)
     float* t_out;
-    void* idx_out;
+    void* idx_out;                // IdxT per ray: voxel index of the hit, all ones = miss
     uint8_t* shadowed_out;
     unsigned long long* next_item;   // work counter
 };
+struct WalkParams {
+    WalkHot hot;
+    WalkCold cold;
+};
+typedef const WalkCold __attribute__((address_space(4)))* WalkColdPtr;
+__device__ __forceinline__ WalkColdPtr walk_cold()
+{
+    const char __attribute__((address_space(4)))* p = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return (WalkColdPtr)(p + offsetof(WalkParams, cold));
+}
 
+#ifdef VX_W_DEBUG
+// diagnostic build: lane utilisation per code site.  site i: g_walk_dbg[2i] = times a wave executed the site, [2i+1] = lanes active
+// over those executions.  Sites: 0 ray set-up, 1 mip lookup, 2 slab step, 3 brick, 4 candidate slab, 5 exact test, 6 retire, 7 round
+// (lanes busy); [16..19] wave cycles in refill / walk / brick / retire.
+__device__ unsigned long long g_walk_dbg[24];
+#define VX_W_SITE(i) { const unsigned long long m_ = __ballot(true); if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) { dbg_w[i] += 1u; dbg_l[i] += (unsigned)__popcll(m_); } }
+#define VX_W_SITE_DECL , unsigned* dbg_w, unsigned* dbg_l
+#define VX_W_SITE_ARGS , dbg_w, dbg_l
+#define VX_W_T(i) { const unsigned long long now_ = __builtin_readcyclecounter(); dbg_c[i] += now_ - dbg_last; dbg_last = now_; }
+#else
+#define VX_W_SITE(i)
+#define VX_W_SITE_DECL
+#define VX_W_SITE_ARGS
+#define VX_W_T(i)
+#endif
+
+#ifndef VOXHIP_DONATE_ON
+#define VOXHIP_DONATE_ON (P.donate != 0)
+#endif
 #ifndef VX_W_STEPS
-#define VX_W_STEPS 6
+#define VX_W_STEPS 4
+#endif
+#ifndef VX_W_ITERS
+#define VX_W_ITERS 2
 #endif
 #ifndef VX_W_REFILL
 #define VX_W_REFILL 48
@@ -324,28 +391,87 @@ struct WalkParams {
 #define VX_W_BLOCK 256
 #endif
 #ifndef VX_W_MINWAVES
-#define VX_W_MINWAVES 1
+#define VX_W_MINWAVES 4
 #endif
 
-// One slab of the walk.  Returns false when the ray is finished.
-template <bool LDS_MIPS>
-__device__ __forceinline__ bool walk_step(WalkLane& R, const WalkParams& P, const uint32_t* __restrict__ mips_lds)
+// After a slab has been dealt with: on to the next one -- and up to the block level at the end of a block slab's eight brick
+// slabs.  Returns false when the walk leaves the grid.
+template <typename IdxT>
+__device__ __forceinline__ bool walk_advance(WalkLane<IdxT>& R)
 {
+    const int s = R.iw > 0.0f ? 1 : -1;
+    const int k = R.k;
+    int nl = 1, kn = k + s;
+    if (R.lvl == 2 || (kn >> 3) != (k >> 3)) { nl = 2; kn = (R.lvl == 2 ? k : (k >> 3)) + s; }
+    const int ncw = (R.dimw + (nl == 2 ? 63 : 7)) >> (nl == 2 ? 6 : 3);
+    if (kn < 0 || kn >= ncw) return false;  // left the grid
+    R.lvl = nl;
+    R.k = kn;
+    return true;
+}
+
+// Level 0, entering a brick: the brick's eight slab words are ONE 64-byte line (four 16-byte loads in flight together -- the
+// walk is bound by dependent memory round trips, not by issue); slabs whose word misses the rectangle the ray sweeps across the
+// whole brick slab are dropped here without any arithmetic.
+template <typename IdxT>
+__device__ __forceinline__ void walk_fetch_brick(WalkLane<IdxT>& R, const WalkHot& P VX_W_SITE_DECL)
+{
+    VX_W_SITE(3)
+    const int nu = (int)((R.pend >> 16) & 0x7FFFu);
+    const int j = R.jb + __ffs(R.pend & 0xFFFFu) - 1;
+    int jv = 0, ju = j;  // j = jv * nu + ju, by subtraction (nu >= 1)
+    while (ju >= nu) { ju -= nu; ++jv; }
+    const int cu = (int)(R.pc & 0xFFFFu) + ju, cv = (int)(R.pc >> 16) + jv;
+    int bx, by, bz;
+    unperm(R.perm, cu, cv, R.k, bx, by, bz);
+    const uint32_t bi = (uint32_t)bx + P.d1[0] * ((uint32_t)by + P.d1[1] * (uint32_t)bz);
+    const ulonglong2* wp = reinterpret_cast<const ulonglong2*>(P.bricks3 + (uint64_t)R.perm * P.ori_stride + (uint64_t)bi * 8ull);
+    const ulonglong2 w01 = wp[0], w23 = wp[1], w45 = wp[2], w67 = wp[3];
+    const int bu = cu << 3, bv = cv << 3;
+    const int u0 = (int)(R.pu & 0xFFFFu), u1 = (int)(R.pu >> 16), v0 = (int)(R.pv & 0xFFFFu), v1 = (int)(R.pv >> 16);
+    const int a0 = (u0 > bu ? u0 : bu) - bu, a1 = (u1 < bu + 7 ? u1 : bu + 7) - bu;  // columns of the brick slab's rectangle inside this brick
+    const int b0 = (v0 > bv ? v0 : bv) - bv, b1 = (v1 < bv + 7 ? v1 : bv + 7) - bv;  // rows
+    const unsigned long long col = (unsigned long long)((2u << a1) - (1u << a0)) * 0x0101010101010101ull;
+    const unsigned long long rect = col & (~0ull >> (8 * (7 - b1))) & (~0ull << (8 * b0));
+    R.w0 = w01.x; R.w1 = w01.y; R.w2 = w23.x; R.w3 = w23.y; R.w4 = w45.x; R.w5 = w45.y; R.w6 = w67.x; R.w7 = w67.y;
+    R.sm = ((w01.x & rect) ? 1u : 0u) | ((w01.y & rect) ? 2u : 0u) | ((w23.x & rect) ? 4u : 0u) | ((w23.y & rect) ? 8u : 0u) |
+           ((w45.x & rect) ? 16u : 0u) | ((w45.y & rect) ? 32u : 0u) | ((w67.x & rect) ? 64u : 0u) | ((w67.y & rect) ? 128u : 0u);
+    R.pc = (R.pc & 0u) | (uint32_t)cu | ((uint32_t)cv << 16);  // from here on: the brick itself (its rectangle cell is popped from R.pend below)
+}
+
+// One step of the walk = one slab: a block slab (level 2), a brick slab (level 1), or one 1-cell slab of the brick being walked
+// (level 0).  All three share the slab's [ta, tb], the termination test and the rectangle of cells; they differ in what the
+// rectangle is looked up in.  Returns false when the ray is finished.
+template <bool LDS_MIPS, typename IdxT>
+__device__ __forceinline__ bool walk_step(WalkLane<IdxT>& R, const WalkHot& P, const uint32_t* __restrict__ mips_lds VX_W_SITE_DECL)
+{
+    VX_W_SITE(2)
     const GridParams& g = P.g;
-    const int lvl = R.lvl, sh = 3 * lvl, k = R.k;
+    const int lvl = R.lvl;
     const bool pos = R.iw > 0.0f;
-    // ---- the slab's [ta, tb] along the major axis
+    // ---- which slab
+    int sl = 0;
+    const bool brick_empty = lvl == 0 && R.sm == 0u;  // nothing (left) of this brick inside the rectangle
+    if (lvl == 0 && !brick_empty) {
+        sl = pos ? (__ffs(R.sm) - 1) : (31 - __clz(R.sm));  // next candidate slab of the brick in travel order
+        R.sm &= ~(1u << sl);
+    }
+    const int sh = lvl == 2 ? 6 : (lvl == 1 ? 3 : 0);
+    const int k = lvl == 0 ? (R.k << 3) + sl : R.k;
     const int i0 = k << sh;
     int i1 = (k + 1) << sh;
     i1 = i1 > R.dimw ? R.dimw : i1;
+    // ---- the slab's [ta, tb] along the major axis
     const float lo = (R.orgw + (float)i0 * g.vs) - R.tol, hi = (R.orgw + (float)i1 * g.vs) + R.tol;
     const float t_lo = R.iw * (lo - R.ow), t_hi = R.iw * (hi - R.ow);
     const float ta = pos ? t_lo : t_hi, tb = pos ? t_hi : t_lo;
-    if (R.best < ta || ta > R.tf) return false;  // no box of this slab or any later one can beat the best hit / beyond the interval
+    const bool stop = brick_empty || R.best < ta || ta > R.tf;  // no box of this slab or any later one can beat the best hit / beyond the interval
+    if (stop && lvl != 0) return false;
+    // (level 0: only this brick is done -- another brick of the same brick slab may still hold an earlier cell)
     const float ca = fmaxf(ta, R.tn), cb = fminf(tb, R.tf);
-    bool any = false;
-    if (ca <= cb) {
-        // ---- the rectangle of cells (of this level) the ray can touch inside the slab
+    bool brick_done = lvl == 0 && (stop || R.sm == 0u);
+    if (ca <= cb && !stop) {
+        // ---- the rectangle of cells the ray can touch inside the slab
         const float tol2 = 2.0f * R.tol;
         const float ua = R.ou + ca * R.du, ub = R.ou + cb * R.du;
         const float va = R.ov + ca * R.dv, vb = R.ov + cb * R.dv;
@@ -355,82 +481,153 @@ __device__ __forceinline__ bool walk_step(WalkLane& R, const WalkParams& P, cons
         v0 = v0 < 0 ? 0 : v0;
         u1 = u1 > R.dimu - 1 ? R.dimu - 1 : u1;
         v1 = v1 > R.dimv - 1 ? R.dimv - 1 : v1;
-        // candidates are looked up in a mip: blocks at level 2, bricks at levels 1 AND 0 (a level-0 slab reads the slab words of the
-        // occupied bricks its rectangle touches)
-        const int shc = lvl == 0 ? 3 : sh;
-        const int cu0 = u0 >> shc, cu1 = u1 >> shc, cv0 = v0 >> shc, cv1 = v1 >> shc;  // (u1, v1 may be -1: arithmetic shift keeps them negative)
-        const int kc = lvl == 0 ? (k >> 3) : k;
-        const bool top = lvl == 2;
-        const uint32_t Dx = top ? P.d2[0] : P.d1[0], Dy = top ? P.d2[1] : P.d1[1];
-        const uint32_t moff = top ? P.m1_words : 0u;
-        for (int cv = cv0; cv <= cv1; ++cv) {
-            for (int cu = cu0; cu <= cu1; ++cu) {
-                int x, y, z;
-                unperm(R.perm, cu, cv, kc, x, y, z);
-                const uint32_t i = (uint32_t)x + Dx * ((uint32_t)y + Dy * (uint32_t)z);
-                const uint32_t wd = LDS_MIPS ? mips_lds[moff + (i >> 5)] : (top ? P.w2[i >> 5] : P.w1[i >> 5]);
-                if (!((wd >> (i & 31u)) & 1u)) continue;
-                if (lvl != 0) { any = true; continue; }
-                // ---- level 0: the slab's word of this brick, the rectangle as a bit mask, exact tests on what survives
-                const unsigned long long bits = P.bricks3[(uint64_t)R.perm * P.ori_stride + (uint64_t)i * 8ull + (uint32_t)(k & 7)];
-                const int bu = cu << 3, bv = cv << 3;
-                const int a0 = (u0 > bu ? u0 : bu) - bu, a1 = (u1 < bu + 7 ? u1 : bu + 7) - bu;  // columns inside the brick
-                const int b0 = (v0 > bv ? v0 : bv) - bv, b1 = (v1 < bv + 7 ? v1 : bv + 7) - bv;  // rows
+        if (lvl == 0) {
+            // ---- level 0: the rectangle inside the brick as a bit mask on the slab's word; exact tests on what survives
+            // (selection BY VALUE: `c ? R.a : R.b` on struct members is an lvalue conditional -- clang selects the address and the lane
+            // state ends up in scratch memory)
+            const unsigned long long bits = sel8(sl, R.w0, R.w1, R.w2, R.w3, R.w4, R.w5, R.w6, R.w7);
+            const int bu = (int)(R.pc & 0xFFFFu) << 3, bv = (int)(R.pc >> 16) << 3;
+            int a0 = u0 - bu, a1 = u1 - bu, b0 = v0 - bv, b1 = v1 - bv;
+            a0 = a0 < 0 ? 0 : a0; b0 = b0 < 0 ? 0 : b0;
+            a1 = a1 > 7 ? 7 : a1; b1 = b1 > 7 ? 7 : b1;
+            unsigned long long cand = 0ull;
+            if (a0 <= a1 && b0 <= b1) {
                 const unsigned long long col = (unsigned long long)((2u << a1) - (1u << a0)) * 0x0101010101010101ull;
-                const unsigned long long rowsel = (~0ull >> (8 * (7 - b1))) & (~0ull << (8 * b0));
-                unsigned long long cand = bits & col & rowsel;
+                cand = bits & col & (~0ull >> (8 * (7 - b1))) & (~0ull << (8 * b0));
+            }
+            if (cand) {
+                // the slab's own box planes along w (voxelgridBool.cpp:37-41: c -/+ half with c = org + (i + 0.5) * vs) and their hitAabb terms
+                const float cw = R.orgw + (((float)k + 0.5f) * g.vs);
+                const float bw = R.iw * ((cw - g.half) - R.ow), tw = R.iw * ((cw + g.half) - R.ow);
+                const float mnw = fminf(tw, bw), mxw = fmaxf(tw, bw);
                 while (cand) {
+                    VX_W_SITE(5)
                     const int b = __ffsll((long long)cand) - 1;
                     cand &= cand - 1ull;
+                    const int cu_ = bu + (b & 7), cv_ = bv + (b >> 3);
+                    const float ccu = R.orgu + (((float)cu_ + 0.5f) * g.vs), ccv = R.orgv + (((float)cv_ + 0.5f) * g.vs);
+                    const float bu_ = R.iu * ((ccu - g.half) - R.ou), tu_ = R.iu * ((ccu + g.half) - R.ou);
+                    const float bv_ = R.iv * ((ccv - g.half) - R.ov), tv_ = R.iv * ((ccv + g.half) - R.ov);
+                    // hitAabb, rint:46-56: t0 = max of the per-axis minima, t1 = min of the per-axis maxima (any axis order: same floats)
+                    const float t0 = fmaxf(fmaxf(fminf(tu_, bu_), fminf(tv_, bv_)), mnw);
+                    const float t1 = fminf(fminf(fmaxf(tu_, bu_), fmaxf(tv_, bv_)), mxw);
+                    const float t = t1 > fmaxf(t0, 0.0f) ? t0 : -1.0f;
                     int cx, cy, cz;
-                    unperm(R.perm, bu + (b & 7), bv + (b >> 3), k, cx, cy, cz);
-                    float bb[6];
-                    cell_aabb(g, (uint32_t)cx, (uint32_t)cy, (uint32_t)cz, bb);
-                    const float o3[3] = {R.ox, R.oy, R.oz}, inv3[3] = {R.ix, R.iy, R.iz};
-                    const float t = hit_aabb(bb, o3, inv3);                       // rint:46-56
-                    const uint64_t vi = (uint64_t)(uint32_t)cx + (uint64_t)g.dim[0] * ((uint64_t)(uint32_t)cy + (uint64_t)g.dim[1] * (uint64_t)(uint32_t)cz);
+                    unperm(R.perm, cu_, cv_, k, cx, cy, cz);
+                    const IdxT vi = (IdxT)(uint32_t)cx + (IdxT)g.dim[0] * ((IdxT)(uint32_t)cy + (IdxT)g.dim[1] * (IdxT)(uint32_t)cz);
                     if (t > 0.0f && t >= P.tmin && t <= R.tmax &&                 // rint:69, rgen:50-51
                         (t < R.best || (t == R.best && vi < R.best_idx))) {
                         R.best = t;
                         R.best_idx = vi;
                     }
                 }
+                if (P.any_hit && R.best_idx != (IdxT)~(IdxT)0) return false;  // shadow query (gl_RayFlagsTerminateOnFirstHitEXT, raytrace2.rchit:108)
+            }
+        } else {
+            const bool top = lvl == 2;
+            const int cu0 = u0 >> sh, cv0 = v0 >> sh;
+            const int nu = (u1 >> sh) - cu0 + 1, nv = (v1 >> sh) - cv0 + 1;  // (u1, v1 may be -1: the arithmetic shift keeps them negative)
+            const int n = (nu > 0 && nv > 0) ? nu * nv : 0;                  // 1 .. 4 cells of this level as a rule, 9 at most
+            const uint32_t Dx = top ? P.d2[0] : P.d1[0], Dy = top ? P.d2[1] : P.d1[1];
+            const uint32_t moff = top ? P.m1_words : 0u;
+            // The rectangle is looked at in windows of 16 cells.  One window is all there ever is unless the position tolerance is
+            // comparable to a brick (coordinates of ~10^6 voxel sizes, where float32 no longer resolves the voxels anyway); the
+            // window logic only keeps that regime correct, not fast.
+            const int jb = R.jb;
+            int ju = jb, jv = 0;
+            while (ju >= nu && nu > 0) { ju -= nu; ++jv; }
+            const int jend = n < jb + 16 ? n : jb + 16;
+            uint32_t occ = 0u;  // bit j - jb: cell (cu0 + j % nu, cv0 + j / nu) of the rectangle is occupied
+#pragma nounroll
+            for (int j = jb; j < jend; ++j) {
+                VX_W_SITE(1)
+                int x, y, z;
+                unperm(R.perm, cu0 + ju, cv0 + jv, k, x, y, z);
+                const uint32_t i = (uint32_t)x + Dx * ((uint32_t)y + Dy * (uint32_t)z);
+                const uint32_t wd = LDS_MIPS ? mips_lds[moff + (i >> 5)] : (top ? P.w2[i >> 5] : P.w1[i >> 5]);
+                occ |= ((wd >> (i & 31u)) & 1u) << (j - jb);
+                if (++ju == nu) { ju = 0; ++jv; }
+            }
+            const bool more = jend < n;
+            if (occ) {
+                if (top) {  // down into the eight brick slabs of this block slab
+                    const int ncw = (R.dimw + 7) >> 3;
+                    int kf = pos ? (k << 3) : (k << 3) + 7;
+                    kf = kf > ncw - 1 ? ncw - 1 : kf;
+                    R.lvl = 1;
+                    R.k = kf;
+                    R.jb = 0;
+                    return true;
+                }
+                // the occupied bricks of this brick slab's rectangle: walked one after the other at level 0
+                R.pend = occ | ((uint32_t)nu << 16) | (more ? 0x80000000u : 0u);
+                R.pc = (uint32_t)cu0 | ((uint32_t)cv0 << 16);
+                R.pu = (uint32_t)u0 | ((uint32_t)u1 << 16);
+                R.pv = (uint32_t)v0 | ((uint32_t)v1 << 16);
+                R.lvl = 0;
+                R.sm = 0u;
+                brick_done = true;  // "no brick loaded yet": fetch the first one below
+            } else if (more) {  // next window of the same slab
+                R.jb = jend;
+                return true;
             }
         }
-        if (P.any_hit && R.best_idx != ~0ull) return false;  // shadow query (gl_RayFlagsTerminateOnFirstHitEXT, raytrace2.rchit:108)
     }
-    // ---- next slab: down into the eight finer slabs of an occupied rectangle, else on (and up when the parent's slabs are done)
-    if (any) {
-        const int nl = lvl - 1;
-        const int ncw = (R.dimw + (1 << (3 * nl)) - 1) >> (3 * nl);
-        int kf = pos ? (k << 3) : (k << 3) + 7;
-        kf = kf > ncw - 1 ? ncw - 1 : kf;
-        R.lvl = nl;
-        R.k = kf;
-        return true;
+    if (R.lvl == 0) {
+        // ---- level 0 bookkeeping: next brick of the brick slab's rectangle once this one is done; back to level 1 after the last
+        if (!brick_done) return true;
+        if (lvl == 0) {  // the brick just finished: pop it; R.pc goes back to the rectangle's first brick for the decode of the next one
+            const uint32_t low = R.pend & 0xFFFFu;
+            const uint32_t rest = low & (low - 1u);
+            // recover (cu0, cv0): the finished brick was rectangle cell j = jb + ffs(low) - 1
+            const int nu = (int)((R.pend >> 16) & 0x7FFFu);
+            int jv = 0, ju = R.jb + __ffs(low) - 1;
+            while (ju >= nu) { ju -= nu; ++jv; }
+            R.pc = (uint32_t)((int)(R.pc & 0xFFFFu) - ju) | ((uint32_t)((int)(R.pc >> 16) - jv) << 16);
+            R.pend = (R.pend & 0xFFFF0000u) | rest;
+        }
+        if (R.pend & 0xFFFFu) {
+            walk_fetch_brick(R, P VX_W_SITE_ARGS);  // (a brick with nothing inside the rectangle is popped by the next step)
+            return true;
+        }
+        const bool more = (R.pend >> 31) != 0u;
+        R.pend = 0u;
+        R.lvl = 1;
+        if (more) { R.jb += 16; return true; }  // the same brick slab's next window of rectangle cells
     }
-    const int s = pos ? 1 : -1;
-    int nl = lvl, kk = k, kn = k + s;
-    if (nl < 2 && (kn >> 3) != (kk >> 3)) { ++nl; kk >>= 3; kn = kk + s; }
-    if (nl < 2 && (kn >> 3) != (kk >> 3)) { ++nl; kk >>= 3; kn = kk + s; }
-    const int ncw = (R.dimw + (1 << (3 * nl)) - 1) >> (3 * nl);
-    if (kn < 0 || kn >= ncw) return false;  // left the grid
-    R.lvl = nl;
-    R.k = kn;
-    return true;
+    R.jb = 0;
+    return walk_advance(R);
 }
+
+// position of the n-th (0-based) set bit of a 64-bit mask (n < popcount)
+__device__ __forceinline__ int nth_set_bit64_w(unsigned long long m, int n)
+{
+    int pos = 0;
+    unsigned lo = (unsigned)m;
+    int c = __popc(lo);
+    if (n >= c) { n -= c; pos = 32; lo = (unsigned)(m >> 32); }
+    c = __popc(lo & 0xFFFFu); if (n >= c) { n -= c; pos += 16; lo >>= 16; }
+    c = __popc(lo & 0xFFu);   if (n >= c) { n -= c; pos += 8;  lo >>= 8; }
+    c = __popc(lo & 0xFu);    if (n >= c) { n -= c; pos += 4;  lo >>= 4; }
+    c = __popc(lo & 0x3u);    if (n >= c) { n -= c; pos += 2;  lo >>= 2; }
+    c = lo & 1u;              if (n >= c) { pos += 1; }
+    return pos;
+}
+__device__ __forceinline__ float shfl_fw(float v, int src) { return __shfl(v, src, 64); }
 
 // Persistent waves with dynamic work fetch.  Exit condition every wave reaches: the work counter passes the ray count (no
 // refill possible) and every lane's ray has finished; a ray finishes in a bounded number of slabs (its index along the major
-// axis is monotone at every level).
-template <bool LDS_MIPS>
-__global__ __launch_bounds__(VX_W_BLOCK, VX_W_MINWAVES) void k_walk(const WalkParams P)
+// axis is monotone at both levels).
+template <bool LDS_MIPS, typename IdxT>
+__global__ __launch_bounds__(VX_W_BLOCK, VX_W_MINWAVES) void k_walk(const WalkParams PP)
 {
-    constexpr int kStepsPerRound = VX_W_STEPS;   // slab steps between two refill checks
+    const WalkHot& P = PP.hot;
+    constexpr int kStepsPerRound = VX_W_STEPS;   // slab steps between two brick phases
+    constexpr int kItersPerRound = VX_W_ITERS;   // (walk, brick) iterations between two refill checks
     constexpr int kRefillBelow = VX_W_REFILL;    // refill when fewer than this many lanes are busy
-    constexpr int kChunkRays = VX_W_CHUNK;       // rays a wave reserves per touch of the global counter: at least ...
-    constexpr int kChunkMax = VX_W_CHUNK_MAX;    // ... and at most
-    constexpr unsigned kWavesPerBlock = VX_W_BLOCK / 64;
+    constexpr uint32_t kChunkRays = VX_W_CHUNK;      // rays a wave reserves per touch of the global counter: at least ...
+    constexpr uint32_t kChunkMax = VX_W_CHUNK_MAX;   // ... and at most
+    constexpr uint32_t kWavesPerBlock = VX_W_BLOCK / 64;
     const GridParams& g = P.g;
     extern __shared__ __attribute__((aligned(16))) uint32_t mips_lds[];
     if (LDS_MIPS) {
@@ -438,27 +635,40 @@ __global__ __launch_bounds__(VX_W_BLOCK, VX_W_MINWAVES) void k_walk(const WalkPa
         for (uint32_t i = threadIdx.x; i < P.m2_words; i += VX_W_BLOCK) mips_lds[P.m1_words + i] = P.w2[i];
         __syncthreads();
     }
+    // Work donation (drain phase): the pieces of a split ray stay inside their wave and meet in LDS -- a 64-bit minimum of
+    // (t bits << 32 | voxel index), the same "closest, then lower index" order a single walk uses, and a piece count; the piece
+    // that finishes last writes the ray's outputs.  Slot = the lane that held the ray when it was first split.
+    constexpr bool kDonate = sizeof(IdxT) == 4;       // the merge key holds the voxel index in 32 bits
+    constexpr int kDonateBelow = 48;                  // donate while at most this many lanes are busy
+    constexpr float kDonateBricks = 6.0f;             // ... and only from pieces with more than this many brick slabs left
+    __shared__ unsigned long long don_key[VX_W_BLOCK];
+    __shared__ unsigned don_cnt[VX_W_BLOCK];
     const int lane = threadIdx.x & 63;
-    WalkLane R;
-    uint64_t r = ~0ull;      // ray this lane is tracing (~0: none)
-    bool busy = false;       // traversal in progress
-    bool drained = false;    // no ray left for this wave: the global counter and the wave's chunk are exhausted
+    int slot = -1;             // >= 0: this lane walks a PIECE of a split ray; its result goes through don_key[slot]
+    WalkLane<IdxT> R;
+    R.pend = 0u;
+#ifdef VX_W_DEBUG
+    unsigned dbg_w[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbg_l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long dbg_c[4] = {0, 0, 0, 0}, dbg_last = __builtin_readcyclecounter();
+#endif
+    uint32_t r = 0xFFFFFFFFu;  // ray this lane is tracing
+    bool busy = false;         // traversal in progress
+    bool drained = false;      // no ray left for this wave: the global counter and the wave's chunk are exhausted
     bool drained_global = false;
-    uint64_t chunk_cur = 0, chunk_end = 0;
-    const uint64_t nrays = P.nrays;
+    uint32_t chunk_cur = 0, chunk_end = 0;
+    const uint32_t nrays = P.nrays;
     // The first chunk of every wave is assigned statically: thousands of waves asking the one counter in the same microsecond
     // queue up behind each other at the memory-side atomic unit.
-    uint64_t static_rays;
+    uint32_t static_rays;
     {
-        uint64_t csz = nrays / (2ull * kWavesPerBlock * gridDim.x);
-        csz = csz > (uint64_t)kChunkMax ? (uint64_t)kChunkMax : csz;
-        csz = csz < (uint64_t)kChunkRays ? (uint64_t)kChunkRays : (csz & ~63ull);
-        static_rays = csz * kWavesPerBlock * gridDim.x;
-        chunk_cur = csz * ((uint64_t)kWavesPerBlock * blockIdx.x + (threadIdx.x >> 6));
-        chunk_end = chunk_cur + csz;
-        if (chunk_end > nrays) chunk_end = nrays;
-        if (chunk_cur > chunk_end) chunk_cur = chunk_end;
-        if (static_rays >= nrays) drained_global = true;
+        uint32_t csz = nrays / (2u * kWavesPerBlock * gridDim.x);
+        csz = csz > kChunkMax ? kChunkMax : csz;
+        csz = csz < kChunkRays ? kChunkRays : (csz & ~63u);
+        const uint64_t sr = (uint64_t)csz * kWavesPerBlock * gridDim.x, c0 = (uint64_t)csz * ((uint64_t)kWavesPerBlock * blockIdx.x + (threadIdx.x >> 6));
+        static_rays = sr > nrays ? nrays : (uint32_t)sr;
+        chunk_cur = c0 > nrays ? nrays : (uint32_t)c0;
+        chunk_end = c0 + csz > nrays ? nrays : (uint32_t)(c0 + csz);
+        if (sr >= nrays) drained_global = true;
     }
     for (;;) {
         const unsigned long long busy_mask = __ballot(busy);
@@ -466,111 +676,236 @@ __global__ __launch_bounds__(VX_W_BLOCK, VX_W_MINWAVES) void k_walk(const WalkPa
         if (!drained && nbusy < kRefillBelow) {
             // ---- refill idle lanes.  Ray indices come from a per-wave chunk; the global counter is touched once per chunk.
             const unsigned long long idle_mask = ~busy_mask;
-            const uint64_t need = (uint64_t)(64 - nbusy);
-            const uint64_t take = need < chunk_end - chunk_cur ? need : chunk_end - chunk_cur;
-            const uint64_t first = chunk_cur;
+            const uint32_t need = (uint32_t)(64 - nbusy);
+            const uint32_t take = need < chunk_end - chunk_cur ? need : chunk_end - chunk_cur;
+            const uint32_t first = chunk_cur;
             chunk_cur += take;
-            uint64_t second = 0;
+            uint32_t second = 0xFFFFFFFFu;
             if (take < need && !drained_global) {
                 // Guided chunk size: the wave waits ~2 us for the counter's old value, so it asks for a large chunk while much is
                 // left (half an even share of what remained at its previous fetch) and for the minimum near the end.
-                const uint64_t left = nrays > chunk_end ? nrays - chunk_end : 0;
-                uint64_t csz = left / (2ull * kWavesPerBlock * gridDim.x);
-                csz = csz > (uint64_t)kChunkMax ? (uint64_t)kChunkMax : csz;
-                csz = csz < (uint64_t)kChunkRays ? (uint64_t)kChunkRays : (csz & ~63ull);
+                const uint32_t left = nrays > chunk_end ? nrays - chunk_end : 0u;
+                uint32_t csz = left / (2u * kWavesPerBlock * gridDim.x);
+                csz = csz > kChunkMax ? kChunkMax : csz;
+                csz = csz < kChunkRays ? kChunkRays : (csz & ~63u);
                 unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(P.next_item, (unsigned long long)csz);
+                if (lane == 0) base = atomicAdd(walk_cold()->next_item, (unsigned long long)csz);
                 base = (((unsigned long long)__shfl((unsigned)(base >> 32), 0, 64) << 32) | __shfl((unsigned)base, 0, 64)) + static_rays;
-                second = base;
-                chunk_cur = base + (need - take);
-                chunk_end = base + csz;
-                if (chunk_end > nrays) chunk_end = nrays > base ? nrays : base;
-                if (chunk_cur > chunk_end) chunk_cur = chunk_end;
+                if (base < nrays) {
+                    second = (uint32_t)base;
+                    chunk_cur = second + (need - take);
+                    chunk_end = base + csz > nrays ? nrays : (uint32_t)(base + csz);
+                    if (chunk_cur > chunk_end) chunk_cur = chunk_end;
+                }
                 if (base + csz >= nrays) drained_global = true;
             }
             if (drained_global && chunk_cur >= chunk_end) drained = true;
             if (!busy) {
-                const uint64_t posn = (uint64_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
-                const uint64_t mine = posn < take ? first + posn : (second ? second + (posn - take) : nrays);
-                if (mine < nrays && (posn < take || mine < chunk_end)) {
+                const uint32_t posn = (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
+                uint32_t mine = 0xFFFFFFFFu;
+                if (posn < take) mine = first + posn;
+                else if (second != 0xFFFFFFFFu && second + (posn - take) < chunk_end) mine = second + (posn - take);
+                if (mine != 0xFFFFFFFFu) {
+                    VX_W_SITE(0)
                     r = mine;
-                    load_ray_w(P.rays == nullptr, r, P.rays, P.cam, R.ox, R.oy, R.oz, R.dx, R.dy, R.dz);
-                    const float tmax_r = P.tmax_per_ray ? P.tmax_per_ray[r] : P.tmax;
-                    busy = walk_setup(R, g, P.d2, P.inv_vs, tmax_r);
+                    const WalkColdPtr C = walk_cold();
+                    const uint64_t ro = C->ray_base + r;
+                    const float* rays = C->rays;
+                    float ox, oy, oz, dx, dy, dz;
+                    load_ray_w(rays == nullptr, ro, rays, C->cam, ox, oy, oz, dx, dy, dz);
+                    const float* tpr = C->tmax_per_ray;
+                    const float tmax_r = tpr ? tpr[ro] : C->tmax;
+                    busy = walk_setup(R, g, P.inv_vs, tmax_r, ox, oy, oz, dx, dy, dz);
                     if (!busy) {  // cannot touch the grid: retire at once
-                        if (P.t_out) P.t_out[r] = -1.0f;
-                        if (P.idx_out) { if (P.idx32) ((uint32_t*)P.idx_out)[r] = 0xFFFFFFFFu; else ((unsigned long long*)P.idx_out)[r] = ~0ull; }
-                        if (P.shadowed_out) P.shadowed_out[r] = 0;
-                        r = ~0ull;
+                        float* t_out = C->t_out;
+                        IdxT* idx_out = (IdxT*)C->idx_out;
+                        uint8_t* shadowed_out = C->shadowed_out;
+                        if (t_out) t_out[ro] = -1.0f;
+                        if (idx_out) idx_out[ro] = (IdxT)~(IdxT)0;
+                        if (shadowed_out) shadowed_out[ro] = 0;
                     }
                 }
             }
         }
+        VX_W_T(0)
         if (!__ballot(busy)) {
             if (drained) break;
             continue;
         }
+        if (busy) { VX_W_SITE(7) }
+        // ---- work donation (drain phase).  With a few rays per lane the queue empties early and every wave is left with a few
+        // long rays on a shrinking set of lanes.  Once no new ray can be fetched, a busy lane with enough of its t interval left
+        // hands the FAR half to an idle lane of its wave (the ray's state travels by shuffles); each piece walks the slabs that
+        // overlap its part of the interval (the slab that holds the cut is looked at by both).
+        if (kDonate && drained) {
+            const unsigned long long bm = __ballot(busy);
+            const int nb = __popcll(bm);
+            if (nb <= kDonateBelow && VOXHIP_DONATE_ON) {
+                const bool pos = R.iw > 0.0f;
+                const int sh = R.lvl == 2 ? 6 : 3;
+                int ip = pos ? (R.k << sh) : ((R.k + 1) << sh);
+                ip = ip > R.dimw ? R.dimw : ip;
+                const float t_cur = fmaxf(R.iw * (((R.orgw + (float)ip * g.vs) + (pos ? -R.tol : R.tol)) - R.ow), R.tn);  // the current slab's ta
+                const float t_end = fminf(R.tf, R.best);
+                const bool can = busy && R.lvl != 0 && (t_end - t_cur > kDonateBricks * 8.0f * g.vs * fabsf(R.iw));
+                const unsigned long long dm = __ballot(can);
+                const unsigned long long im = ~bm;
+                const int ndon = min(__popcll(dm), 64 - nb);
+                if (ndon > 0) {
+                    const unsigned long long lt = (1ull << lane) - 1ull;
+                    const bool donor = can && __popcll(dm & lt) < ndon;
+                    const float t_mid = 0.5f * (t_cur + t_end);
+                    if (donor) {
+                        if (slot < 0) {  // first split of this ray: open its merge slot (this piece counts as one)
+                            slot = (int)threadIdx.x;
+                            don_key[slot] = ~0ull;
+                            don_cnt[slot] = 1u;
+                        }
+                        atomicAdd(&don_cnt[slot], 1u);  // the piece handed out below
+                    }
+                    const int irank = __popcll(im & lt);
+                    const bool recv = !busy && irank < ndon;
+                    const int src = nth_set_bit64_w(dm, recv ? irank : 0);
+                    const float s_ou = shfl_fw(R.ou, src), s_ov = shfl_fw(R.ov, src), s_ow = shfl_fw(R.ow, src), s_du = shfl_fw(R.du, src), s_dv = shfl_fw(R.dv, src);
+                    const float s_iu = shfl_fw(R.iu, src), s_iv = shfl_fw(R.iv, src), s_iw = shfl_fw(R.iw, src);
+                    const float s_orgu = shfl_fw(R.orgu, src), s_orgv = shfl_fw(R.orgv, src), s_orgw = shfl_fw(R.orgw, src);
+                    const int s_dimu = __shfl(R.dimu, src, 64), s_dimv = __shfl(R.dimv, src, 64), s_dimw = __shfl(R.dimw, src, 64), s_perm = __shfl(R.perm, src, 64);
+                    const float s_tol = shfl_fw(R.tol, src), s_tmax = shfl_fw(R.tmax, src), s_best = shfl_fw(R.best, src), s_mid = shfl_fw(t_mid, src), s_end = shfl_fw(t_end, src);
+                    const uint32_t s_bidx = __shfl((uint32_t)R.best_idx, src, 64), s_r = __shfl(r, src, 64);
+                    const int s_slot = __shfl(slot, src, 64);
+                    if (donor) R.tf = t_mid;  // keep the near half
+                    if (recv) {
+                        R.ou = s_ou; R.ov = s_ov; R.ow = s_ow; R.du = s_du; R.dv = s_dv; R.iu = s_iu; R.iv = s_iv; R.iw = s_iw;
+                        R.orgu = s_orgu; R.orgv = s_orgv; R.orgw = s_orgw; R.dimu = s_dimu; R.dimv = s_dimv; R.dimw = s_dimw; R.perm = s_perm;
+                        R.tol = s_tol; R.tmax = s_tmax; R.best = s_best; R.best_idx = (IdxT)s_bidx;
+                        R.tn = s_mid; R.tf = s_end;
+                        R.pend = 0u; R.jb = 0; R.sm = 0u; R.lvl = 2;
+                        // first block slab of the piece: the one that holds the cut (one cell of slack, as in walk_setup)
+                        const float pw = s_ow + s_mid * (1.0f / s_iw);
+                        int cw = (int)floorf((pw - s_orgw) * P.inv_vs) + (s_iw > 0.0f ? -1 : 1);
+                        cw = cw < 0 ? 0 : (cw > s_dimw - 1 ? s_dimw - 1 : cw);
+                        R.k = cw >> 6;
+                        r = s_r;
+                        slot = s_slot;
+                        busy = true;
+                    }
+                }
+            }
+        }
         // ---- walk: every busy lane advances by one slab per step, whatever its level
         bool finished = false;
-        for (int s = 0; s < kStepsPerRound; ++s) {
+        for (int s = 0; s < kStepsPerRound * kItersPerRound; ++s) {
             const bool go = busy && !finished;
             if (!__ballot(go)) break;
-            if (go && !walk_step<LDS_MIPS>(R, P, mips_lds)) finished = true;
+            if (go && !walk_step<LDS_MIPS>(R, P, mips_lds VX_W_SITE_ARGS)) finished = true;
         }
+        VX_W_T(1)
         // ---- retire: t and the voxel index of the hit; the primitive rank (two dependent loads), the normal and the hit
         // compaction are done by k_rank over all rays afterwards, off this kernel's critical path
-        if (finished) {
-            const bool hit = R.best_idx != ~0ull;
-            if (P.t_out) P.t_out[r] = hit ? R.best : -1.0f;
-            if (P.idx_out) { if (P.idx32) ((uint32_t*)P.idx_out)[r] = hit ? (uint32_t)R.best_idx : 0xFFFFFFFFu; else ((unsigned long long*)P.idx_out)[r] = R.best_idx; }
-            if (P.shadowed_out) P.shadowed_out[r] = hit ? 1 : 0;
-            busy = false;
-            r = ~0ull;
+        if (__ballot(finished)) {
+            const WalkColdPtr C = walk_cold();
+            if (finished) {
+                VX_W_SITE(6)
+                bool hit = R.best_idx != (IdxT)~(IdxT)0;
+                float best_t = R.best;
+                IdxT best_i = R.best_idx;
+                bool write = true;
+                if (kDonate && slot >= 0) {
+                    // a piece of a split ray: merge, and only the piece that finishes last reports
+                    if (hit) atomicMin(&don_key[slot], ((unsigned long long)__float_as_uint(R.best) << 32) | (unsigned long long)(uint32_t)R.best_idx);
+                    write = atomicSub(&don_cnt[slot], 1u) == 1u;
+                    if (write) {
+                        const unsigned long long key = don_key[slot];
+                        hit = key != ~0ull;
+                        best_t = __uint_as_float((uint32_t)(key >> 32));
+                        best_i = hit ? (IdxT)(uint32_t)key : (IdxT)~(IdxT)0;
+                    }
+                    slot = -1;
+                }
+                if (write) {
+                    const uint64_t ro = C->ray_base + r;
+                    float* t_out = C->t_out;
+                    IdxT* idx_out = (IdxT*)C->idx_out;
+                    uint8_t* shadowed_out = C->shadowed_out;
+                    if (t_out) t_out[ro] = hit ? best_t : -1.0f;
+                    if (idx_out) idx_out[ro] = best_i;
+                    if (shadowed_out) shadowed_out[ro] = hit ? 1 : 0;
+                }
+                busy = false;
+            }
         }
+        VX_W_T(3)
     }
+#ifdef VX_W_DEBUG
+    for (int i = 0; i < 8; ++i) {
+        unsigned a = dbg_w[i], b = dbg_l[i];
+        for (int m = 32; m >= 1; m >>= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
+        if (lane == 0) { atomicAdd(&g_walk_dbg[2 * i], (unsigned long long)a); atomicAdd(&g_walk_dbg[2 * i + 1], (unsigned long long)b); }
+    }
+    if (lane == 0) for (int i = 0; i < 4; ++i) atomicAdd(&g_walk_dbg[16 + i], dbg_c[i]);
+#endif
 }
+
+#ifdef VX_W_DEBUG
+}  // namespace vx
+extern "C" int vx_debug_walk(unsigned long long* out24, int reset)
+{
+    if (out24 && hipMemcpyFromSymbol(out24, HIP_SYMBOL(vx::g_walk_dbg), 24 * 8) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[24] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(vx::g_walk_dbg), z, 24 * 8) != hipSuccess) return 1; }
+    return 0;
+}
+namespace vx {
+#endif
 
 void launch_walk(const GridParams& g, const TraceMips& mips, const unsigned long long* bricks3, const TraceIO& io, unsigned long long* counter,
                  void* idx_out, bool idx32, hipStream_t s)
 {
-    const uint64_t nrays = io.nrays;
-    if (!nrays) return;
-    (void)hipMemsetAsync(counter, 0, sizeof(unsigned long long), s);
+    if (!io.nrays) return;
     const uint64_t n1 = (uint64_t)mips.d1[0] * mips.d1[1] * mips.d1[2], n2 = (uint64_t)mips.d2[0] * mips.d2[1] * mips.d2[2];
     const uint32_t m1_words = (uint32_t)((n1 + 31) / 32), m2_words = (uint32_t)((n2 + 31) / 32);
     // VOXHIP_TRACE_LDS=0 forces the global-memory mips (the path every grid above ~550^3 takes) -- used by the parity tests
     const char* env_lds = getenv("VOXHIP_TRACE_LDS");
-    const bool lds = (size_t)(m1_words + m2_words) * 4 <= 40960 && !(env_lds && atoi(env_lds) == 0);
+    const bool lds = (size_t)(m1_words + m2_words) * 4 <= 32768 + 1024 && !(env_lds && atoi(env_lds) == 0);
     const int env_blocks = getenv("VOXHIP_TRACE_BLOCKS") ? atoi(getenv("VOXHIP_TRACE_BLOCKS")) : 0;
-    const uint64_t max_blocks = env_blocks > 0 ? (uint64_t)env_blocks : 1024ull * 256ull / VX_W_BLOCK;
-    uint64_t nblk = (nrays + VX_W_BLOCK - 1) / VX_W_BLOCK;
-    if (nblk > max_blocks) nblk = max_blocks;
     WalkParams P;
     std::memset(&P, 0, sizeof(P));
-    P.g = g;
-    P.bricks3 = bricks3;
-    P.ori_stride = n1 * 8ull;
-    P.w1 = mips.w1;
-    P.w2 = mips.w2;
-    for (int a = 0; a < 3; ++a) { P.d1[a] = mips.d1[a]; P.d2[a] = mips.d2[a]; }
-    P.inv_vs = 1.0f / g.vs;
-    P.tmin = io.tmin;
-    P.any_hit = io.any_hit ? 1 : 0;
-    P.m1_words = m1_words;
-    P.m2_words = m2_words;
-    P.rays = io.rays;
-    P.cam = io.cam_dev;
-    P.tmax_per_ray = io.tmax_per_ray;
-    P.tmax = io.tmax;
-    P.idx32 = idx32 ? 1u : 0u;
-    P.nrays = nrays;
-    P.t_out = io.t_out;
-    P.idx_out = idx_out;
-    P.shadowed_out = io.shadowed_out;
-    P.next_item = counter;
+    P.hot.g = g;
+    P.hot.bricks3 = bricks3;
+    P.hot.ori_stride = n1 * 8ull;
+    P.hot.w1 = mips.w1;
+    P.hot.w2 = mips.w2;
+    for (int a = 0; a < 3; ++a) { P.hot.d1[a] = mips.d1[a]; P.hot.d2[a] = mips.d2[a]; }
+    P.hot.inv_vs = 1.0f / g.vs;
+    P.hot.tmin = io.tmin;
+    P.hot.any_hit = io.any_hit ? 1 : 0;
+    P.hot.m1_words = m1_words;
+    P.hot.m2_words = m2_words;
+    P.hot.donate = (getenv("VOXHIP_TRACE_DONATE") ? atoi(getenv("VOXHIP_TRACE_DONATE")) : 1) ? 1 : 0;
+    P.cold.rays = io.rays;
+    P.cold.cam = io.cam_dev;
+    P.cold.tmax_per_ray = io.tmax_per_ray;
+    P.cold.tmax = io.tmax;
+    P.cold.t_out = io.t_out;
+    P.cold.idx_out = idx_out;
+    P.cold.shadowed_out = io.shadowed_out;
+    P.cold.next_item = counter;
     const size_t shmem = lds ? (size_t)(m1_words + m2_words) * 4 : 0;
-    const dim3 grid((unsigned)nblk), block(VX_W_BLOCK);
-    if (lds) { VX_KL(k_walk<true>, grid, block, shmem, s, P); } else { VX_KL(k_walk<false>, grid, block, shmem, s, P); }
+    // one launch per 2^31 rays: ray indices inside the kernel are 32-bit
+    for (uint64_t base = 0; base < io.nrays; base += 0x80000000ull) {
+        const uint64_t n = io.nrays - base < 0x80000000ull ? io.nrays - base : 0x80000000ull;
+        P.hot.nrays = (uint32_t)n;
+        P.cold.ray_base = base;
+        (void)hipMemsetAsync(counter, 0, sizeof(unsigned long long), s);
+        const uint64_t max_blocks = env_blocks > 0 ? (uint64_t)env_blocks : 256ull * VX_W_MINWAVES * 4ull * 64ull / VX_W_BLOCK;  // one resident set of waves
+        uint64_t nblk = (n + VX_W_BLOCK - 1) / VX_W_BLOCK;
+        if (nblk > max_blocks) nblk = max_blocks;
+        const dim3 grid((unsigned)nblk), block(VX_W_BLOCK);
+        if (lds) {
+            if (idx32) VX_KL((k_walk<true, uint32_t>), grid, block, shmem, s, P); else VX_KL((k_walk<true, unsigned long long>), grid, block, shmem, s, P);
+        } else {
+            if (idx32) VX_KL((k_walk<false, uint32_t>), grid, block, shmem, s, P); else VX_KL((k_walk<false, unsigned long long>), grid, block, shmem, s, P);
+        }
+    }
 }
 
 }  // namespace vx
