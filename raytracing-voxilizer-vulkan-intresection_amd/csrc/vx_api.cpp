@@ -241,7 +241,7 @@ struct vx_grid {
     float bbmin[3] = {0, 0, 0}, bbmax[3] = {0, 0, 0}, bbc[3] = {0, 0, 0};
     uint64_t triangles = 0;
     uint32_t cdim[3] = {0, 0, 0}, c2dim[3] = {0, 0, 0};
-    DevBuf words, cwords, c2words, bricks, bbounds, idxtmp, ttmp, spill, keys, camera, wprefix, recs, units, ubase, btri, umask, hbase, scantmp, small, vec;
+    DevBuf words, cwords, c2words, bricks, idxtmp, ttmp, camera, wprefix, recs, units, ubase, btri, umask, hbase, scantmp, small, vec;
     bool coarse_valid = false, prefix_valid = false /*word_prefix queued or done*/, occupied_known = false, counts_valid = true;
     uint64_t occupied = 0, set_calls = 0, host_set_calls = 0;
     uint64_t vec_count = 0;
@@ -249,18 +249,18 @@ struct vx_grid {
     void set_dev(int d)
     {
         device = d;
-        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &bbounds, &idxtmp, &ttmp, &spill, &keys, &camera, &wprefix, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec}) b->dev = d;
+        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &idxtmp, &ttmp, &camera, &wprefix, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec}) b->dev = d;
     }
     // the stream this handle queues work on; the pool orders the reuse of released blocks by it
     void set_stream(hipStream_t st)
     {
         if (st != stream && words.p) (void)hipStreamSynchronize(stream);  // work queued on the old stream must not outlive the switch
         stream = st;
-        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &bbounds, &idxtmp, &ttmp, &spill, &keys, &camera, &wprefix, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec}) b->stream = st;
+        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &idxtmp, &ttmp, &camera, &wprefix, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec}) b->stream = st;
     }
     void release_all()
     {
-        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &bbounds, &idxtmp, &ttmp, &spill, &keys, &camera, &wprefix, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec}) b->release();
+        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &idxtmp, &ttmp, &camera, &wprefix, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec}) b->release();
         if (mail) (void)hipHostFree(mail);
         mail = nullptr;
     }
@@ -415,11 +415,10 @@ vx_status ensure_coarse(vx_grid* g)
     const uint64_t nc2 = (uint64_t)g->c2dim[0] * g->c2dim[1] * g->c2dim[2];
     VX_HIP(g->cwords.ensure((size_t)((nc + 63) / 64 * 2 + 2) * 4));
     VX_HIP(g->c2words.ensure((size_t)((nc2 + 31) / 32 + 2) * 4));
-    VX_HIP(g->bricks.ensure((size_t)(nc * 8 * 3 + 8) * 8));  // three orientations (x, y, z slabs); the z one is what the bounds kernel reads
-    VX_HIP(g->bbounds.ensure((size_t)(nc + 8) * 4));
-    // bitmask -> brick-major slabs in three orientations -> per-brick bounds + level-1 mip -> level-2 mip
+    VX_HIP(g->bricks.ensure((size_t)(nc * 8 * 3 + 8) * 8));  // three orientations (x, y, z slabs)
+    // bitmask -> brick-major slabs in three orientations -> level-1 mip (from the z orientation) -> level-2 mip
     vx::launch_build_bricks3(g->words.as<uint32_t>(), g->g.dim, g->cdim, g->bricks.as<unsigned long long>(), g->stream);
-    vx::launch_brick_bounds(g->bricks.as<unsigned long long>() + 2ull * nc * 8ull, nc, g->bbounds.as<uint32_t>(), g->cwords.as<uint32_t>(), g->stream);
+    vx::launch_brick_mip1(g->bricks.as<unsigned long long>() + 2ull * nc * 8ull, nc, g->cwords.as<uint32_t>(), g->stream);
     vx::launch_build_mip2(g->cwords.as<uint32_t>(), g->cdim, g->c2dim, g->c2words.as<uint32_t>(), g->stream);
     g->coarse_valid = true;
     return VX_OK;
@@ -955,22 +954,20 @@ static vx_status trace_common(vx_grid* g, vx::TraceIO io)
 {
     VX_TRY(ensure_coarse(g));
     const uint32_t* prefix = nullptr;
-    unsigned long long* idx_tmp = nullptr;
+    void* idx_tmp = nullptr;
     if (io.prim_out || io.hits || io.normal_out) {
         bool pending = false;
         VX_TRY(prefix_launch(g, &pending));  // the ranks need the prefix array on the stream, not the count on the host
         prefix = g->wprefix.as<uint32_t>();
-        VX_HIP(g->idxtmp.ensure((size_t)io.nrays * 8 + 8));
-        idx_tmp = g->idxtmp.as<unsigned long long>();
+        VX_HIP(g->idxtmp.ensure(vx::trace_idx_bytes(g->g, io.nrays)));
+        idx_tmp = g->idxtmp.p;
         if (!io.t_out) {  // the rank / normal / compaction pass reads t
             VX_HIP(g->ttmp.ensure((size_t)io.nrays * 4 + 8));
             io.t_out = g->ttmp.as<float>();
         }
     }
     vx::TraceMips mips;
-    const uint64_t nbricks = (uint64_t)g->cdim[0] * g->cdim[1] * g->cdim[2];
-    mips.bricks = g->bricks.as<unsigned long long>() + 2ull * nbricks * 8ull;  // z orientation
-    mips.bounds = g->bbounds.as<uint32_t>();
+    mips.bricks3 = g->bricks.as<unsigned long long>();
     mips.w0 = g->words.as<uint32_t>();
     mips.w1 = g->cwords.as<uint32_t>();
     mips.w2 = g->c2words.as<uint32_t>();
@@ -981,16 +978,7 @@ static vx_status trace_common(vx_grid* g, vx::TraceIO io)
         VX_HIP(hipStreamSynchronize(g->stream));  // the host copy lives on the caller's stack
         io.cam_dev = g->camera.as<vx::Camera>();
     }
-    if (!vx::trace_uses_walk()) {  // scratch of the round-1 DDA's work donation
-        VX_HIP(g->spill.ensure(vx::trace_spill_bytes(io.nrays)));
-        if (g->spill.fresh) {  // split flags: all zero between launches (the merge step clears what the trace sets)
-            VX_HIP(hipMemsetAsync(g->spill.p, 0, g->spill.cap, g->stream));
-            g->spill.fresh = false;
-        }
-        VX_HIP(g->keys.ensure((size_t)io.nrays * 8 + 8));
-    }
-    vx::launch_trace(g->g, mips, g->bricks.as<unsigned long long>(), prefix, io, g->small.as<Small>()->trace_counters, idx_tmp, g->spill.p,
-                     g->keys.as<unsigned long long>(), g->stream);
+    vx::launch_trace(g->g, mips, prefix, io, g->small.as<Small>()->trace_counters, idx_tmp, g->stream);
     VX_HIP(hipGetLastError());
     return VX_OK;
 }

@@ -17,7 +17,7 @@ struct __attribute__((aligned(16))) TriRec {
 };
 static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
 
-constexpr uint32_t kCoarse = 8;        // fine cells per coarse cell edge (ray traversal mip)
+constexpr uint32_t kCoarse = 8;        // cells per brick edge, bricks per block edge (ray traversal structure)
 constexpr uint32_t kCoarseShift = 3;
 constexpr int kScanBlock = 256;
 constexpr int kScanItems = 8;          // elements per thread in the scan kernels
@@ -82,21 +82,18 @@ void launch_emit_bool_aabbs(const uint32_t* words, const uint32_t* word_prefix, 
 // AABBs from sorted Morton items (Octree::getAabbs)
 void launch_emit_morton_aabbs(const uint64_t* items, uint64_t n, const float root_min[3], float vs, vx_aabb* out, hipStream_t s);
 
-// occupancy mip for the ray kernel: one bit per 8^3 cells of the level below (fdim = dims of that level)
-void launch_build_mip2(const uint32_t* m1, const uint32_t d1[3], const uint32_t d2[3], uint32_t* m2, hipStream_t s);
-
-// K6: first hit per ray.  Three-level occupancy hierarchy: cells (bricks; w0 = the reference-layout bitmask, used for the
-// primitive rank only), 8^3 bricks (w1, dims d1), 64^3 blocks (w2, dims d2).
-void launch_build_bricks(const uint32_t* words, const uint32_t dim[3], const uint32_t bdim[3], unsigned long long* bricks, hipStream_t s);
-// the same in three orientations, one per possible major axis of a ray: bricks3[ori][brick][slab along ori], ori 0 x / 1 y / 2 z;
-// orientation 2 is launch_build_bricks' layout (bit y*8+x per z slab), orientation 0 has bit z*8+y per x slab, orientation 1 bit x*8+z
+// ---- K6: first hit per ray (vx_walk.hip) and the structure it walks --------------------------------------------------------
+// Traversal structure = the analogue of the reference's BLAS build (hello_vulkan.cpp:737-760), three levels:
+//   bricks3  the bitmask re-tiled brick-major (8^3 cells) in three orientations, one per possible major axis of a ray:
+//            bricks3[ori][brick][slab along ori], ori 0 x / 1 y / 2 z; orientation 2 holds bit y*8+x per z slab, orientation 0
+//            bit z*8+y per x slab, orientation 1 bit x*8+z per y slab
+//   w1       one bit per brick (dims d1), x-fastest;   w2: one bit per 8^3 bricks (dims d2)
 void launch_build_bricks3(const uint32_t* words, const uint32_t dim[3], const uint32_t bdim[3], unsigned long long* bricks3, hipStream_t s);
-// also writes the level-1 mip (one bit per brick, x-fastest, (nbricks+63)/64*2 words)
-void launch_brick_bounds(const unsigned long long* bricks, uint64_t nbricks, uint32_t* bounds, uint32_t* m1, hipStream_t s);
+void launch_brick_mip1(const unsigned long long* bricks_z /*orientation 2*/, uint64_t nbricks, uint32_t* m1, hipStream_t s);
+void launch_build_mip2(const uint32_t* m1, const uint32_t d1[3], const uint32_t d2[3], uint32_t* m2, hipStream_t s);
 struct TraceMips {
-    const uint32_t* bounds;            // per brick: packed bounding box of its occupied cells
-    const unsigned long long* bricks;  // level 0 re-tiled brick-major: one uint64 per (8^3 brick, z slice)
-    const uint32_t* w0;
+    const unsigned long long* bricks3;
+    const uint32_t* w0;                // the reference-layout bitmask (primitive rank only)
     const uint32_t* w1;
     const uint32_t* w2;
     uint32_t d1[3];
@@ -117,11 +114,11 @@ struct TraceIO {
     vx_hit* hits = nullptr;
     unsigned long long* nhits = nullptr;
 };
-size_t trace_spill_bytes(uint64_t nrays);
-bool trace_uses_walk();  // slab walk (default) or the round-1 DDA (VOXHIP_TRACE_ALGO=dda): decides which scratch buffers are needed
-void launch_trace(const GridParams& g, const TraceMips& mips, const unsigned long long* bricks3, const uint32_t* word_prefix, const TraceIO& io,
-                  unsigned long long* counters /*4 device words*/, unsigned long long* idx_tmp /*nrays x 8 B when ranks are wanted*/,
-                  void* spill_buf /*trace_spill_bytes(nrays), DDA only*/, unsigned long long* keys /*nrays x 8 B, DDA only*/, hipStream_t s);
+// voxel indices of the hits travel from the walk to the rank pass as 32-bit words when they fit (all ones = miss)
+inline bool trace_idx32(const GridParams& g) { return g.nvox < 0xFFFFFFFFull; }
+inline size_t trace_idx_bytes(const GridParams& g, uint64_t nrays) { return (size_t)nrays * (trace_idx32(g) ? 4 : 8) + 8; }
+void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* word_prefix, const TraceIO& io, unsigned long long* counters /*1 device word*/,
+                  void* idx_tmp /*trace_idx_bytes when ranks / normals / the hit list are wanted*/, hipStream_t s);
 
 // single-voxel helpers
 void launch_set_bit(uint32_t* words, uint64_t idx, hipStream_t s);

@@ -7,7 +7,7 @@
 // the lanes of a wave, and provably a superset of the cells whose float boxes the ray can enter:
 //
 //   Let w be the axis of the largest |direction| component, u and v the other two.  The grid is cut into slabs perpendicular to
-//   w at three granularities: 64 cells (blocks, level 2), 8 cells (bricks, level 1), 1 cell (level 0).  For a slab with lattice
+//   w at three granularities: 64 cells (block slabs, level 2), 8 cells (brick slabs, level 1), 1 cell (level 0).  For a slab with lattice
 //   planes P_near, P_far (in travel order) the ray is within the position tolerance `tol` of the slab for
 //        t in [ta, tb],  ta = inv_w * ((P_near -/+ tol) - o_w),  tb = inv_w * ((P_far +/- tol) - o_w)
 //   -- the same expression form as hitAabb's `invDir * (plane - origin)` (rint:49-50), so by monotonicity of float subtraction
@@ -16,21 +16,28 @@
 //        [min(p(ta), p(tb)) - 2 tol, max(p(ta), p(tb)) + 2 tol]
 //   (|d_u|, |d_v| <= |d_w|: an error in t moves the point by less than the same error along w; no 1/d_u blow-up exists, and a
 //   zero component simply gives a constant coordinate), so the cells the ray can touch in the slab lie in that rectangle --
-//   1x1 .. 2x2 cells of the slab's granularity, 3x3 at worst.  A step of the walk = one slab: its rectangle is looked up in the
-//   occupancy mip of its level; an occupied rectangle descends to the eight finer slabs, an empty one moves on.  At level 0 the
-//   rectangle's occupied cells go through the exact rint formula on the float box the reference would have built for them,
-//   which is the only arbiter of hit and t -- the reported t is the very float the brute-force minimum yields.
+//   1x1 .. 2x2 cells of the slab's granularity, 3x3 at worst.
 //
-// Data layout (built once per bitmask by k_build_bricks3 / k_brick_bounds / k_build_mip2, the analogue of the reference's BLAS
+// A step of the walk = one slab, the same code at every level: the slab's [ta, tb], the termination test, the rectangle.  A
+// block slab (level 2) or brick slab (level 1) looks its rectangle up in the occupancy mip of its level; an occupied block
+// rectangle descends to its eight brick slabs; the occupied bricks of a brick slab's rectangle are walked one after the other at
+// level 0.  Entering a brick costs ONE 64-byte line -- its eight slab words -- and drops the slabs whose word misses the
+// rectangle the ray sweeps across the whole brick; each remaining slab ANDs its own (tighter) rectangle with its word, and the
+// surviving cells go through the exact rint formula on the float box the reference would have built for them, which is the only
+// arbiter of hit and t -- the reported t is the very float the brute-force minimum yields.
+//
+// Data layout (built once per bitmask by k_build_bricks3 / k_brick_mip1 / k_build_mip2, the analogue of the reference's BLAS
 // build, hello_vulkan.cpp:737-760):
 //   level 0  "bricks": the bitmask re-tiled brick-major in THREE orientations, one per possible major axis: for orientation w one
 //            uint64 per (8x8x8 brick, slab along w), bit = (v&7)*8 + (u&7) with (u, v) = the axes after w cyclically.  Whatever
-//            the ray's major axis, the cells of a 1-cell slab inside a brick are ONE 8-byte load.
+//            the ray's major axis, a brick is one contiguous 64-byte line of eight slab words.
 //   level 1  one bit per brick, x-fastest; level 2 one bit per 8^3 bricks; both staged in LDS by every workgroup when they fit.
 //
 // Wave efficiency.  Persistent waves; a lane whose ray has finished takes the next ray of its wave's chunk of a global queue
-// (first chunk static, later ones by one atomicAdd of a guided size).  Every active lane executes the same slab step whatever
-// its level; only the exact tests (1.7 per ray on the bench scene) diverge.
+// (first chunk static, later ones by one atomicAdd of a guided size).  Every busy lane executes the same slab step whatever its
+// level; only the mip lookups, the brick fetch and the exact tests (1.7 per ray on the bench scene) diverge.  Once the queue is
+// dry, lanes with a long interval left hand its far half to idle lanes of their wave; the pieces meet in LDS.  Measured history
+// and lane-utilisation figures: DESIGN.md section 4.
 //
 // No MFMA: this is traversal, not a contraction.  Algorithmic HBM traffic is the ray stream (24 B in, 4-8 B out per ray).
 #include "vx_internal.h"
@@ -857,8 +864,7 @@ extern "C" int vx_debug_walk(unsigned long long* out24, int reset)
 namespace vx {
 #endif
 
-void launch_walk(const GridParams& g, const TraceMips& mips, const unsigned long long* bricks3, const TraceIO& io, unsigned long long* counter,
-                 void* idx_out, bool idx32, hipStream_t s)
+void launch_walk(const GridParams& g, const TraceMips& mips, const TraceIO& io, unsigned long long* counter, void* idx_out, bool idx32, hipStream_t s)
 {
     if (!io.nrays) return;
     const uint64_t n1 = (uint64_t)mips.d1[0] * mips.d1[1] * mips.d1[2], n2 = (uint64_t)mips.d2[0] * mips.d2[1] * mips.d2[2];
@@ -870,7 +876,7 @@ void launch_walk(const GridParams& g, const TraceMips& mips, const unsigned long
     WalkParams P;
     std::memset(&P, 0, sizeof(P));
     P.hot.g = g;
-    P.hot.bricks3 = bricks3;
+    P.hot.bricks3 = mips.bricks3;
     P.hot.ori_stride = n1 * 8ull;
     P.hot.w1 = mips.w1;
     P.hot.w2 = mips.w2;

@@ -187,3 +187,53 @@ def test_brute_force_inner_form_equals_hit_aabb():
             o[z[0]] = box["mn"][z[0]]
         a_, b_ = oracle.hit_aabb(box, o, d), oracle.hit_aabb_fast(box, o, d)
         assert (a_ == b_) or (np.isnan(a_) and np.isnan(b_)), (k, a_, b_, box, o, d)
+
+
+@pytest.mark.parametrize("name,vs", [("cube", 0.25), ("cube", 0.0625), ("rotcube", 0.09), ("adversarial", 0.0625), ("soup2000", 0.02), ("blob70k", 2.0 / 64)])
+def test_grid_walk_equals_brute_force(name, vs):
+    """oracle/vx_walk.c -- the CPU statement of the traversal the HIP kernel k_walk implements (major-axis slab walk + the exact
+    rint formula) and bench.py's CPU stand-in for the ray stage -- returns the brute-force minimum bit for bit: random,
+    lattice-corner-aimed, near-axis-parallel, inside-the-grid rays and rays with exactly-zero direction components."""
+    from test_gpu_configs import aimed_rays, zero_component_rays
+    from test_gpu_parity import axis_rays, corner_rays, inside_rays
+    v, t = vx_scenes.scene(name)
+    vs = np.float32(vs)
+    ow, _, gi = oracle.build_bool(v, t, vs, threads=4)
+    oa = oracle.bool_aabbs(ow, gi, vs)
+    n = 1500
+    for rays in (vx_scenes.random_rays(n, gi["bmin"], gi["bmax"], seed=2), corner_rays(gi, float(vs), n, 5), axis_rays(gi, float(vs), n, 6),
+                 inside_rays(gi, float(vs), n, 7), zero_component_rays(oa, gi, vs, 900, 8), aimed_rays(oa, gi, n, 9)):
+        ot, op = oracle.trace_brute(oa, rays)
+        wt, wp = oracle.trace_walk(ow, gi, vs, rays)
+        assert np.array_equal(wt, ot) and np.array_equal(wp, op)
+    for tmin, tmax in ((9.5, 10000.0), (0.001, 9.3)):
+        rays = vx_scenes.random_rays(n, gi["bmin"], gi["bmax"], seed=3)
+        ot, op = oracle.trace_brute(oa, rays, tmin, tmax)
+        wt, wp = oracle.trace_walk(ow, gi, vs, rays, tmin, tmax)
+        assert np.array_equal(wt, ot) and np.array_equal(wp, op)
+
+
+def test_grid_walk_far_from_origin():
+    """Grids far from the origin: the walk's tolerance scales with max |coordinate| and must still enclose every box the
+    brute-force formula can report."""
+    from test_gpu_configs import zero_component_rays
+    from test_gpu_parity import corner_rays, inside_rays
+    rng = np.random.default_rng(77)
+    for case in range(12):
+        n = int(rng.integers(20, 200))
+        scale = float(10.0 ** rng.uniform(-1, 1))
+        off = rng.choice([-1.0, 1.0], 3) * rng.uniform(0.0 if case % 2 else 100.0, 2000.0, 3) * scale
+        v = (rng.uniform(0, 1, (3 * n, 3)) * scale * rng.uniform(0.05, 1.0, 3) + off).astype(np.float32)
+        t = np.arange(3 * n, dtype=np.int32).reshape(-1, 3)
+        ext = float((v.max(0) - v.min(0)).max())
+        vs = np.float32(ext / float(rng.integers(4, 70)))
+        ow, _, gi = oracle.build_bool(v, t, vs)
+        oa = oracle.bool_aabbs(ow, gi, vs)
+        if not len(oa):
+            continue
+        hi = gi["bmin"] + np.array(gi["dim"], np.float32) * vs
+        for rays in (vx_scenes.random_rays(800, gi["bmin"], hi, seed=100 + case), corner_rays(gi, float(vs), 500, case), inside_rays(gi, float(vs), 500, case),
+                     zero_component_rays(oa, gi, vs, 300, case)):
+            ot, op = oracle.trace_brute(oa, rays)
+            wt, wp = oracle.trace_walk(ow, gi, vs, rays)
+            assert np.array_equal(wt, ot) and np.array_equal(wp, op), case

@@ -1,4 +1,5 @@
-mkdir -p gpurun_out/r2g
-python tools/trace_bench.py > gpurun_out/r2g/tb_walk.log 2>&1; tail -1 gpurun_out/r2g/tb_walk.log
-VOXHIP_TRACE_DONATE=0 TB_NOCHECK=1 python tools/trace_bench.py 2>&1 | tail -1
-timeout -k 10 900 python -m pytest tests/test_gpu_configs.py tests/test_gpu_parity.py -m gpu -q -x --timeout 900 -k "trace or ray or shadow or tiny or far or random or reuse or primary or c3 or c4 or c5" > gpurun_out/r2g/pytest.log 2>&1; tail -5 gpurun_out/r2g/pytest.log
+mkdir -p gpurun_out/r2i
+C5_TILES=3 python tools/run_c5.py > gpurun_out/r2i/c5_walk.log 2>&1; grep -E "primary rays|Octree build|VoxelGridBool build|steady" gpurun_out/r2i/c5_walk.log
+C5_TILES=3 VOXHIP_TRACE_ALGO=dda python tools/run_c5.py > gpurun_out/r2i/c5_dda.log 2>&1; grep -E "primary rays" gpurun_out/r2i/c5_dda.log
+TB_GRID=1024 TB_NOCHECK=1 python tools/trace_bench.py 2>&1 | tail -1
+TB_GRID=1024 TB_NOCHECK=1 VOXHIP_TRACE_ALGO=dda python tools/trace_bench.py 2>&1 | tail -1

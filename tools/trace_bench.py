@@ -10,7 +10,8 @@ v, t = vx_scenes.scene("atrium262k")
 vs = np.float32(32.0 / grid)
 g = voxhip.Grid.voxelize(voxhip.Mesh.from_arrays(v, t), vs)
 out = []
-for n in (1_000_000, 8_000_000):
+sizes = [int(x) * 1_000_000 for x in os.environ.get('TB_SIZES', '1,8').split(',')]
+for n in sizes:
     rays_h = vx_scenes.random_rays(n, v.min(0), v.max(0), seed=2)
     rays = torch.from_numpy(rays_h).cuda()
     d_t = torch.empty(n, dtype=torch.float32, device="cuda"); d_p = torch.empty(n, dtype=torch.int32, device="cuda")
