@@ -82,13 +82,18 @@ typedef struct vx_grid_desc {
 typedef struct vx_voxelize_opts {
     int32_t sat_variant;  /* 0: triBoxOverlap (serial driver, VoxelBuilder.hpp:118-162, inParaell=false);
                              1: triBoxOverlapSchwarzSeidel (threaded driver, :226-335, inParaell=true) */
-    int32_t reserved;
+    int32_t flags;        /* VX_VOXELIZE_* bits (0 = the reference as it runs today) */
     uint64_t word_begin;  /* multi-GPU shard: only bitmask words [word_begin, word_end) are written by this    */
     uint64_t word_end;    /* call (both 0 = whole grid).  Triangle range for VX_GRID_VEC shards:               */
     uint64_t tri_begin;   /* only triangles [tri_begin, tri_end) are voxelized (both 0 = all).                 */
     uint64_t tri_end;
     void* stream;         /* hipStream_t the grid's kernels run on */
 } vx_voxelize_opts;
+
+/* vx_voxelize_opts.flags */
+#define VX_VOXELIZE_MATERIALS 1 /* also fill the per-voxel material ids: setVoxel -> addMatrialIfNeeded, the plumbing the reference keeps
+                                   commented out (VoxelBuilder.hpp:375-395, voxelgridBool.cpp:64, voxelgridAABBstruct.cpp:31,
+                                   voxelgridVecEncoding.cpp:27).  Not available for word / triangle shards. */
 
 /* ---- library ------------------------------------------------------------------------------------------- */
 const char* vx_last_error(void);
@@ -150,6 +155,16 @@ vx_status vx_grid_refresh(vx_grid* g);            /* recount + rebuild derived d
  * *count receives the list length; at most `capacity` entries are written (capacity 0 = size query). */
 vx_status vx_grid_aabbs(const vx_grid* g, vx_aabb* host_out, uint64_t capacity, uint64_t* count);
 vx_status vx_grid_aabbs_device(const vx_grid* g, vx_aabb* dev_out, uint64_t capacity, uint64_t* count);
+/* getMatrials() / getMatIdx() (voxelgrid.hpp:74-89) of a grid built with VX_VOXELIZE_MATERIALS:
+ *   materials     the distinct MaterialObj values in the order addMatrialIfNeeded first met them (equality = MaterialObj::operator==,
+ *                 obj_loader.h:45-51: every field except ior and dissolve; a face without usemtl carries MaterialObj{});
+ *   material ids  the entries >= 0 of m_matIdx in index order: for VX_GRID_BOOL / VX_GRID_AABBSTRUCT one int16 per occupied voxel in
+ *                 ascending voxel order (entry i belongs to box i of vx_grid_aabbs; the value is the material of the LAST setVoxel
+ *                 call on that voxel), for VX_GRID_VEC one per setVoxel call in call order (entry i belongs to box i of the list).
+ * Without the flag both are empty, as in the reference today.  *count receives the length; capacity 0 = size query. */
+vx_status vx_grid_materials(const vx_grid* g, vx_material* host_out, uint64_t capacity, uint64_t* count);
+vx_status vx_grid_material_ids(const vx_grid* g, int16_t* host_out, uint64_t capacity, uint64_t* count);
+const int16_t* vx_grid_material_ids_device(const vx_grid* g); /* NULL without materials */
 void vx_grid_free(vx_grid* g);
 
 /* ---- octree: replaces Octree (octTree.hpp:487-523) ------------------------------------------------------- */

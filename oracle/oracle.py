@@ -75,6 +75,10 @@ def lib():
         L.vxo_primary_rays_pixels.argtypes = [fp, fp, C.c_uint32, C.c_uint32, u64p, C.c_uint64, fp]
         L.vxo_trace_any_brute.argtypes = [C.c_void_p, C.c_uint64, fp, C.c_uint64, C.c_float, C.c_float, fp, C.POINTER(C.c_uint8)]
         L.vxo_cube_normal.argtypes = [C.c_void_p, fp, fp, C.c_float, fp]
+        L.vxo_build_material_ids.argtypes = [fp, C.c_size_t, ip, C.c_size_t, C.c_float, C.c_int, ip, C.c_int32, C.c_int, C.c_uint64, C.c_void_p, C.c_uint64, ip,
+                                             C.POINTER(C.c_int32)]
+        L.vxo_build_material_ids.restype = C.c_uint64
+        L.vxo_shade_image.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, fp, C.c_uint64, fp, fp, C.c_uint32, C.c_uint32, fp, C.c_float, C.c_int, fp, C.c_int, C.c_void_p]
         L.vxo_walk_create.argtypes = [u32p, u64p, C.c_float, fp]
         L.vxo_walk_create.restype = C.c_void_p
         L.vxo_walk_free.argtypes = [C.c_void_p]
@@ -307,3 +311,44 @@ def trace_walk(words, gi, vs, rays, tmin=0.001, tmax=10000.0, threads=None, want
     if want_stats:
         return t, p, dict(cell_slabs=int(stats[0]), brick_slabs=int(stats[1]), block_slabs=int(stats[2]), exact_tests=int(stats[3]))
     return t, p
+
+
+def material_ids(verts, idx, vs, tri_value, nvalues, per_call=False, ncalls=0, sat=-1):
+    """The reference's commented-out material plumbing (see vx_oracle.c): -> (getMatIdx() int16[], value ids in getMatrials() order)."""
+    v, i = _mesh(verts, idx)
+    tv = np.ascontiguousarray(tri_value, dtype=np.int32)
+    order = np.zeros(max(nvalues, 1), dtype=np.int32)
+    used = C.c_int32(0)
+    gi = grid_info(v, vs)
+    cap = int(ncalls) if per_call else int(np.prod(gi["dim"]))
+    out = np.zeros(max(cap, 1), dtype=np.int16)
+    n = int(lib().vxo_build_material_ids(_f(v), v.shape[0], _i(i), i.shape[0], np.float32(vs), sat, _i(tv), nvalues, 1 if per_call else 0, int(ncalls),
+                                         out.ctypes.data, cap, _i(order), C.byref(used)))
+    return out[:n], order[:used.value]
+
+
+DEFAULT_MATERIAL = np.array([0.1, 0.1, 0.1, 1, 1, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0.1, 0.0, 1.0, 1.0], dtype=np.float32)  # MaterialObj{} (+ illum 0, texture -1)
+
+
+def shade_image(aabbs, view_inv, proj_inv, W, H, materials=None, mat_idx=None, light_pos=(10.0, 55.0, 8.0), light_intensity=1000.0, light_type=0,
+                clear=(1.0, 1.0, 1.0), threads=None):
+    """The reference's picture of the voxel boxes (rgen + rint + rchit2 + rmiss + post.frag restated): uint8[H, W, 3].
+    materials: records in vx_material layout (80 bytes each) or None = the one default material createAABB uploads."""
+    a = np.ascontiguousarray(aabbs, dtype=AABB)
+    if materials is None or len(materials) == 0:
+        m = np.zeros(20, dtype=np.float32)
+        m[:18] = DEFAULT_MATERIAL
+        m[18:] = np.array([0, -1], dtype=np.int32).view(np.float32)
+        nmat = 1
+    else:
+        m = np.ascontiguousarray(materials).view(np.float32).reshape(-1)
+        nmat = len(materials)
+    mi = None if mat_idx is None else np.ascontiguousarray(mat_idx, dtype=np.int16)
+    vi = np.ascontiguousarray(view_inv, dtype=np.float32).reshape(16)
+    pi = np.ascontiguousarray(proj_inv, dtype=np.float32).reshape(16)
+    lp = np.array(light_pos, dtype=np.float32)
+    cl = np.array(clear, dtype=np.float32)
+    out = np.zeros((H, W, 3), dtype=np.uint8)
+    lib().vxo_shade_image(a.ctypes.data if a.size else None, a.size, mi.ctypes.data if mi is not None else None, _f(m), nmat, _f(vi), _f(pi), W, H, _f(lp),
+                          np.float32(light_intensity), light_type, _f(cl), threads or (os.cpu_count() or 1), out.ctypes.data)
+    return out

@@ -324,6 +324,62 @@ static void run_driver(const float* verts, size_t nverts, const int32_t* idx, si
 }
 
 /* ---------------------------------------------------------------------------------------
+ * per-voxel material ids -- the plumbing the reference keeps commented out, restated as written:
+ *   VoxelBuilder.hpp:375-395   materialId = mesh.material_ids[face] (or -1) -> MaterialObj (default or a copy of m_materials[id])
+ *   setVoxel -> addMatrialIfNeeded(idx, material)        voxelgridBool.cpp:64, voxelgridAABBstruct.cpp:31  (idx = voxel index)
+ *               addMatrialIfNeeded(m_voxelSet, material) voxelgridVecEncoding.cpp:27                       (idx = call number)
+ *   addMatrialIfNeeded         voxelgrid.hpp:102-114     known material -> its index, else the next index; m_matIdx[idx] = index
+ *   getMatIdx                  voxelgrid.hpp:79-89       the entries >= 0 in index order
+ * Materials are passed as VALUE ids (the caller has already identified equal MaterialObj by operator==, obj_loader.h:45-51).
+ * Serial driver order (a9).  per_call = 0: Bool / AABBstruct (one id per occupied voxel); 1: Vec (one id per call).
+ * out_ids receives getMatIdx(); out_values receives, per index, the value id (== getMatrials() as value ids).
+ * Returns the number of ids; *nvalues_used the number of materials.
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+    int16_t* mat_idx; uint64_t n_idx; uint64_t X, Y; int per_call; uint64_t calls;
+    int16_t* value_index; int32_t* values_in_order; int32_t nused; int32_t cur_value;
+} mat_ctx;
+static void mat_set(void* c, uint32_t x, uint32_t y, uint32_t z)
+{
+    mat_ctx* m = (mat_ctx*)c;
+    const uint64_t idx = m->per_call ? m->calls : (x + m->X * (y + m->Y * (uint64_t)z));
+    m->calls++;
+    if (m->value_index[m->cur_value] < 0) {                  /* voxelgrid.hpp:108-112 */
+        m->value_index[m->cur_value] = (int16_t)m->nused;
+        m->values_in_order[m->nused++] = m->cur_value;
+    }
+    if (idx < m->n_idx) m->mat_idx[idx] = m->value_index[m->cur_value];  /* :106 / :113 (the Vec flavour's m_matIdx has X*Y*Z entries) */
+}
+uint64_t vxo_build_material_ids(const float* verts, size_t nverts, const int32_t* idx, size_t ntri, float vs, int sat_override,
+                                const int32_t* tri_value, int32_t nvalues, int per_call, uint64_t ncalls_hint, int16_t* out_ids, uint64_t cap,
+                                int32_t* out_values, int32_t* nvalues_used)
+{
+    vxo_grid_info gi;
+    vxo_grid_info_compute(verts, nverts * 3, vs, &gi);
+    mat_ctx m;
+    memset(&m, 0, sizeof(m));
+    m.X = gi.dim[0]; m.Y = gi.dim[1];
+    m.per_call = per_call;
+    m.n_idx = per_call ? ncalls_hint : gi.dim[0] * gi.dim[1] * gi.dim[2];
+    m.mat_idx = (int16_t*)malloc((size_t)(m.n_idx ? m.n_idx : 1) * sizeof(int16_t));
+    for (uint64_t i = 0; i < m.n_idx; ++i) m.mat_idx[i] = -1;       /* voxelgrid.hpp:59 */
+    m.value_index = (int16_t*)malloc((size_t)(nvalues > 0 ? nvalues : 1) * sizeof(int16_t));
+    for (int32_t i = 0; i < nvalues; ++i) m.value_index[i] = -1;
+    m.values_in_order = out_values;
+    const int ss = sat_override < 0 ? 0 : sat_override;
+    for (size_t t = 0; t < ntri; ++t) {
+        m.cur_value = tri_value[t];
+        voxelize_range(verts, idx, t, t + 1, &gi, vs, ss, 1, mat_set, &m);
+    }
+    uint64_t n = 0;
+    for (uint64_t i = 0; i < m.n_idx; ++i)
+        if (m.mat_idx[i] >= 0) { if (n < cap) out_ids[n] = m.mat_idx[i]; ++n; }
+    if (nvalues_used) *nvalues_used = m.nused;
+    free(m.mat_idx); free(m.value_index);
+    return n;
+}
+
+/* ---------------------------------------------------------------------------------------
  * a11 VoxelGridBool                  voxelgridBool.cpp:11-16 (ctor), :54-68 (setVoxel), :18-52 (getAabbs)
  * ------------------------------------------------------------------------------------- */
 typedef struct { uint32_t* words; uint64_t X, Y; uint64_t set_calls; } bool_ctx;
@@ -740,20 +796,47 @@ void vxo_primary_rays_pixels(const float viewInv[16], const float projInv[16], u
  *                         miss shader (raytraceShadow.rmiss:25-28) runs, i.e. shadowed <=> SOME box reports an accepted hit.
  * Cube-face normal        raytrace2.rchit:60-73.  GLSL leaves contraction of `o + d*t` to the compiler; restated without FMA.
  * ------------------------------------------------------------------------------------- */
+typedef struct { const vxo_aabb* boxes; uint64_t n; const float* rays; uint64_t r0, r1; float tmin, tmax; const float* tmax_per_ray; uint8_t* out; } any_arg;
+static void* any_main(void* p)
+{
+    any_arg* a = (any_arg*)p;
+    for (uint64_t r = a->r0; r < a->r1; ++r) {
+        const float* o = a->rays + 6 * r;
+        const float* d = o + 3;
+        const float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
+        const float tm = a->tmax_per_ray ? a->tmax_per_ray[r] : a->tmax;
+        uint8_t s = 0;
+        for (uint64_t i = 0; i < a->n && !s; ++i) {
+            const float t = hit_aabb_inv(&a->boxes[i], o, inv);   /* == vxo_hit_aabb, see trace_main */
+            if (t > 0.0f && t >= a->tmin && t <= tm) s = 1;
+        }
+        a->out[r] = s;
+    }
+    return NULL;
+}
+void vxo_trace_any_brute_mt(const vxo_aabb* boxes, uint64_t n, const float* rays, uint64_t nrays, float tmin, float tmax,
+                            const float* tmax_per_ray, int threads, uint8_t* shadowed)
+{
+    if (threads < 1) threads = 1;
+    any_arg* aa = (any_arg*)calloc((size_t)threads, sizeof(any_arg));
+    pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
+    const uint64_t chunk = (nrays + (uint64_t)threads - 1) / (uint64_t)threads;
+    int started = 0;
+    for (int t = 0; t < threads; ++t) {
+        const uint64_t b = (uint64_t)t * chunk;
+        if (b >= nrays) break;
+        any_arg x = {boxes, n, rays, b, (b + chunk < nrays) ? b + chunk : nrays, tmin, tmax, tmax_per_ray, shadowed};
+        aa[t] = x;
+        pthread_create(&th[t], NULL, any_main, &aa[t]);
+        ++started;
+    }
+    for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+    free(aa); free(th);
+}
 void vxo_trace_any_brute(const vxo_aabb* boxes, uint64_t n, const float* rays, uint64_t nrays, float tmin, float tmax,
                          const float* tmax_per_ray, uint8_t* shadowed)
 {
-    for (uint64_t r = 0; r < nrays; ++r) {
-        const float* o = rays + 6 * r;
-        const float* d = o + 3;
-        const float tm = tmax_per_ray ? tmax_per_ray[r] : tmax;
-        uint8_t s = 0;
-        for (uint64_t i = 0; i < n && !s; ++i) {
-            const float t = vxo_hit_aabb(&boxes[i], o, d);
-            if (t > 0.0f && t >= tmin && t <= tm) s = 1;
-        }
-        shadowed[r] = s;
-    }
+    vxo_trace_any_brute_mt(boxes, n, rays, nrays, tmin, tmax, tmax_per_ray, 8, shadowed);
 }
 
 static float sign_glsl(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
@@ -774,4 +857,88 @@ void vxo_cube_normal(const vxo_aabb* b, const float o[3], const float d[3], floa
     if (maxC == ax) out[0] = sign_glsl(nx);                    /* :71-73 */
     else if (maxC == ay) out[1] = sign_glsl(ny);
     else out[2] = sign_glsl(nz);
+}
+
+/* ---------------------------------------------------------------------------------------
+ * the picture.  One pixel = raytrace.rgen:39-67 (primary ray, tMin 0.001, tMax 10000) -> closest voxel box
+ * (brute force over the list) -> raytrace2.rchit:53-137 (cube-face normal, point / directional light, material of
+ * matIndices[gl_PrimitiveID], Lambert + ambient for illum >= 1, shadow ray with terminate-on-first-hit and tMax = distance to the
+ * light, attenuation 0.3 in shadow, specular of wavefront.glsl:32-48 when lit) or raytrace.rmiss:37 (clearColor * 0.8) ->
+ * post.frag:33-37 (pow(c, 1/2.2)), stored as 8-bit RGB.  glm / GLSL functions restated in float32: dot = (x*x' + y*y') + z*z',
+ * normalize = v * (1 / sqrt(dot(v, v))), reflect(I, N) = I - 2 dot(N, I) N.
+ * materials: 20 floats per record in vx_material order (ambient, diffuse, specular, transmittance, emission, shininess, ior,
+ * dissolve, illum as int32, texture id as int32); mat_idx NULL = every box uses record 0.
+ * ------------------------------------------------------------------------------------- */
+static float dot3(const float a[3], const float b[3]) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+void vxo_shade_image(const vxo_aabb* boxes, uint64_t n, const int16_t* mat_idx, const float* materials, uint64_t nmat, const float viewInv[16],
+                     const float projInv[16], uint32_t W, uint32_t H, const float light_pos[3], float light_intensity, int light_type, const float clear[3],
+                     int threads, uint8_t* rgb)
+{
+    const uint64_t npx = (uint64_t)W * H;
+    float* rays = (float*)malloc((size_t)npx * 6 * sizeof(float));
+    float* t = (float*)malloc((size_t)npx * sizeof(float));
+    uint32_t* prim = (uint32_t*)malloc((size_t)npx * sizeof(uint32_t));
+    vxo_primary_rays(viewInv, projInv, W, H, rays);
+    vxo_trace_brute(boxes, n, rays, npx, 0.001f, 10000.0f, threads, t, prim);   /* rgen:50-51 */
+    float* srays = (float*)malloc((size_t)npx * 6 * sizeof(float));
+    float* stmax = (float*)malloc((size_t)npx * sizeof(float));
+    uint8_t* shadowed = (uint8_t*)calloc((size_t)npx, 1);
+    for (uint64_t i = 0; i < npx; ++i) {
+        const float* o = rays + 6 * i; const float* d = o + 3;
+        const float tt = t[i] > 0.0f ? t[i] : 0.0f;
+        const float wp[3] = {o[0] + d[0] * tt, o[1] + d[1] * tt, o[2] + d[2] * tt};
+        float L[3]; float dist = 100000.0f;
+        if (light_type == 0) {
+            const float l[3] = {light_pos[0] - wp[0], light_pos[1] - wp[1], light_pos[2] - wp[2]};
+            dist = sqrtf(dot3(l, l));
+            const float il = 1.0f / dist;
+            L[0] = l[0] * il; L[1] = l[1] * il; L[2] = l[2] * il;
+        } else {
+            const float il = 1.0f / sqrtf(dot3(light_pos, light_pos));
+            L[0] = light_pos[0] * il; L[1] = light_pos[1] * il; L[2] = light_pos[2] * il;
+        }
+        srays[6 * i + 0] = wp[0]; srays[6 * i + 1] = wp[1]; srays[6 * i + 2] = wp[2];
+        srays[6 * i + 3] = L[0]; srays[6 * i + 4] = L[1]; srays[6 * i + 5] = L[2];
+        stmax[i] = dist;
+    }
+    vxo_trace_any_brute_mt(boxes, n, srays, npx, 0.001f, 10000.0f, stmax, threads, shadowed);   /* rchit:103-122 */
+    for (uint64_t i = 0; i < npx; ++i) {
+        float c[3] = {clear[0] * 0.8f, clear[1] * 0.8f, clear[2] * 0.8f};          /* rmiss:37 */
+        if (t[i] > 0.0f) {
+            const float* o = rays + 6 * i; const float* d = o + 3;
+            const float* L = srays + 6 * i + 3;
+            float N[3];
+            vxo_cube_normal(&boxes[prim[i]], o, d, t[i], N);                        /* rchit:60-73 */
+            const float dist = stmax[i];
+            const float li = light_type == 0 ? light_intensity / (dist * dist) : light_intensity;   /* rchit:80-90 */
+            const uint64_t mi = mat_idx ? (uint64_t)(mat_idx[prim[i]] < 0 ? 0 : mat_idx[prim[i]]) : 0;
+            const float* m = materials + 20 * (mi < nmat ? mi : 0);
+            const int illum = ((const int32_t*)m)[18];
+            const float dnl = fmaxf(dot3(N, L), 0.0f);                              /* wavefront.glsl:25 */
+            float diff[3] = {m[3] * dnl, m[4] * dnl, m[5] * dnl};
+            if (illum >= 1) { diff[0] += m[0]; diff[1] += m[1]; diff[2] += m[2]; }
+            float att = 0.3f, spec[3] = {0.0f, 0.0f, 0.0f};
+            if (dot3(N, L) > 0.0f && !shadowed[i]) {                                /* rchit:99-133 */
+                att = 1.0f;
+                if (illum >= 2) {                                                   /* wavefront.glsl:32-48 */
+                    const float kPi = 3.14159265f, kSh = fmaxf(m[15], 4.0f);
+                    const float kE = (2.0f + kSh) / (2.0f * kPi);
+                    const float nd[3] = {-d[0], -d[1], -d[2]};
+                    const float iv = 1.0f / sqrtf(dot3(nd, nd));
+                    const float V[3] = {nd[0] * iv, nd[1] * iv, nd[2] * iv};
+                    const float I[3] = {-L[0], -L[1], -L[2]};
+                    const float k2 = 2.0f * dot3(N, I);
+                    const float R[3] = {I[0] - N[0] * k2, I[1] - N[1] * k2, I[2] - N[2] * k2};
+                    const float sp = kE * powf(fmaxf(dot3(V, R), 0.0f), kSh);
+                    spec[0] = m[6] * sp; spec[1] = m[7] * sp; spec[2] = m[8] * sp;
+                }
+            }
+            for (int k = 0; k < 3; ++k) c[k] = li * att * (diff[k] + spec[k]);     /* rchit:136 */
+        }
+        for (int k = 0; k < 3; ++k) {
+            const float cl = fminf(fmaxf(c[k], 0.0f), 1.0f);                        /* 8-bit UNORM target */
+            rgb[3 * i + k] = (uint8_t)lroundf(powf(cl, 1.0f / 2.2f) * 255.0f);      /* post.frag:36 */
+        }
+    }
+    free(rays); free(t); free(prim); free(srays); free(stmax); free(shadowed);
 }

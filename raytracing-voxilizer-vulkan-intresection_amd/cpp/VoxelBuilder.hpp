@@ -64,8 +64,14 @@ public:
         m_mesh.reset(m, vxdetail::MeshDeleter{});
     }
 
+    // Switches on the material plumbing the reference keeps commented out (VoxelBuilder.hpp:375-395, voxelgridBool.cpp:64):
+    // buildVoxelGrid then also fills the grid's getMatrials() / getMatIdx() from the OBJ's usemtl / mtllib.  Off by default, like
+    // the reference today (every voxel MaterialObj{}, nothing recorded).
+    VoxelBuilder& withMaterials(bool on = true) { m_materials = on; return *this; }
+
 private:
     std::shared_ptr<vx_mesh> m_mesh;
+    bool m_materials = false;
 
     void readObjFile(const std::filesystem::path& path)
     {
@@ -83,6 +89,7 @@ public:
         }
         vx_voxelize_opts opts{};
         opts.sat_variant = inParaell ? 1 : 0;
+        opts.flags = m_materials ? VX_VOXELIZE_MATERIALS : 0;
         vx_grid* g = nullptr;
         vxdetail::check(vx_voxelize(m_mesh.get(), voxelSize, vxdetail::kind_of<T>(), &opts, &g));
         vxdetail::GridHandle h = vxdetail::adopt(g);

@@ -110,10 +110,39 @@ public:
         return occ != 0;
     }
 
-    std::vector<MaterialObj> getMatrials() const noexcept { return m_materials; }
+    // voxelgrid.hpp:74-89.  A grid voxelized with materials (VoxelBuilder::withMaterials) answers from the device: the distinct
+    // MaterialObj in first-use order and the ids >= 0 in index order (one per occupied voxel, last setVoxel call wins; VoxelGridVec:
+    // one per call).  Otherwise, as in the reference today, only what addMatrialIfNeeded was called with by hand.
+    std::vector<MaterialObj> getMatrials() const noexcept
+    {
+        uint64_t n = 0;
+        if (vx_grid_materials(m_grid.get(), nullptr, 0, &n) == VX_OK && n) {
+            std::vector<vx_material> raw(n);
+            if (vx_grid_materials(m_grid.get(), raw.data(), n, &n) == VX_OK) {
+                std::vector<MaterialObj> ret(n);
+                for (uint64_t i = 0; i < n; ++i) {
+                    const vx_material& r = raw[i];
+                    MaterialObj& m = ret[i];
+                    m.ambient = vec3(r.ambient[0], r.ambient[1], r.ambient[2]);
+                    m.diffuse = vec3(r.diffuse[0], r.diffuse[1], r.diffuse[2]);
+                    m.specular = vec3(r.specular[0], r.specular[1], r.specular[2]);
+                    m.transmittance = vec3(r.transmittance[0], r.transmittance[1], r.transmittance[2]);
+                    m.emission = vec3(r.emission[0], r.emission[1], r.emission[2]);
+                    m.shininess = r.shininess; m.ior = r.ior; m.dissolve = r.dissolve; m.illum = r.illum; m.textureID = r.texture_id;
+                }
+                return ret;
+            }
+        }
+        return m_materials;
+    }
 
     std::vector<int16_t> getMatIdx() const noexcept
     {
+        uint64_t n = 0;
+        if (vx_grid_material_ids(m_grid.get(), nullptr, 0, &n) == VX_OK && n) {
+            std::vector<int16_t> ret(n);
+            if (vx_grid_material_ids(m_grid.get(), ret.data(), n, &n) == VX_OK) return ret;
+        }
         std::vector<int16_t> ret;
         ret.reserve(m_materials.size());
         for (const auto& kv : m_matIdx)

@@ -12,7 +12,11 @@
 //                                       camera (main.cpp:92, raytrace.rgen:41-51), cube normals + Lambert + shadow ray as in
 //                                       raytrace2.rchit:53-137 with the default material and light (hello_vulkan.h:84-90), miss
 //                                       colour raytrace.rmiss:37, gamma post.frag:36.  Rays run on the GPU, the per-pixel shading
-//                                       arithmetic (display, not the hot path) on the host.
+//                                       arithmetic (display, not the hot path) on the host.  --camera-dump FILE writes the two 4x4
+//                                       matrices used (column-major float32), for comparisons.
+//   --materials                         switch on the reference's commented-out material plumbing (usemtl / mtllib -> per-voxel
+//                                       material ids; VoxelBuilder.hpp:375-395): --render shades with them, --dump-materials FILE writes
+//                                       getMatIdx() as int16
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -56,10 +60,17 @@ void camera(float vi[16], float pi[16], float aspect)
     pi[0] = 1.0f / a; pi[5] = 1.0f / b; pi[11] = 1.0f / d; pi[14] = -1.0f; pi[15] = c / d;  // column-major inverse of the projection
 }
 
-int render(vx_grid* grid, const std::string& file, uint32_t W, uint32_t H)
+struct RenderOpts { std::vector<MaterialObj> materials; std::vector<int16_t> matIdx; std::string cameraDump; };
+
+int render(vx_grid* grid, const std::string& file, uint32_t W, uint32_t H, const RenderOpts& ro)
 {
     float vi[16], pi[16];
     camera(vi, pi, (float)W / (float)H);
+    if (!ro.cameraDump.empty()) {
+        std::ofstream cf(ro.cameraDump, std::ios::binary);
+        cf.write(reinterpret_cast<const char*>(vi), 64);
+        cf.write(reinterpret_cast<const char*>(pi), 64);
+    }
     const size_t n = (size_t)W * H;
     std::vector<float> t(n), nrm(3 * n), rays(6 * n), tmaxs(n);
     std::vector<uint32_t> prim(n);
@@ -83,14 +94,14 @@ int render(vx_grid* grid, const std::string& file, uint32_t W, uint32_t H)
         const float dist = std::sqrt(dot(l, l));
         const V3 L = l * (1.0f / dist);
         rays[6 * i + 0] = wp.x; rays[6 * i + 1] = wp.y; rays[6 * i + 2] = wp.z;
-        rays[6 * i + 3] = L.x == 0.f ? 1e-20f : L.x; rays[6 * i + 4] = L.y == 0.f ? 1e-20f : L.y; rays[6 * i + 5] = L.z == 0.f ? 1e-20f : L.z;
+        rays[6 * i + 3] = L.x; rays[6 * i + 4] = L.y; rays[6 * i + 5] = L.z;
         tmaxs[i] = dist;
     }
     vx_trace_args sa{};
     sa.rays = rays.data(); sa.num_rays = n; sa.tmin = 0.001f; sa.tmax = 10000.0f; sa.tmax_per_ray = tmaxs.data(); sa.any_hit = 1;
     sa.shadowed = shadowed.data();
     vxdetail::check(vx_trace_ex(grid, &sa));
-    const MaterialObj mat{};  // the single default material createAABB uploads (hello_vulkan.cpp:701-702)
+    const MaterialObj defmat{};  // the single default material createAABB uploads (hello_vulkan.cpp:701-702)
     std::vector<unsigned char> img(3 * n);
     size_t hits = 0;
     for (size_t i = 0; i < n; ++i) {
@@ -98,12 +109,27 @@ int render(vx_grid* grid, const std::string& file, uint32_t W, uint32_t H)
         if (t[i] > 0) {
             ++hits;
             const V3 N{nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]}, L{rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]};
+            // matIndices.i[gl_PrimitiveID] -> materials.m[matIdx] (rchit:92-94); without --materials: index 0 of the one default material
+            const MaterialObj& mat = (!ro.matIdx.empty() && prim[i] < ro.matIdx.size() && (size_t)ro.matIdx[prim[i]] < ro.materials.size())
+                                         ? ro.materials[(size_t)ro.matIdx[prim[i]]] : defmat;
             const float li = intensity / (tmaxs[i] * tmaxs[i]);                 // rchit:85
             const float dnl = std::fmax(dot(N, L), 0.0f);                       // wavefront.glsl:25
             float diff[3] = {mat.diffuse.x * dnl, mat.diffuse.y * dnl, mat.diffuse.z * dnl};
             if (mat.illum >= 1) { diff[0] += mat.ambient.x; diff[1] += mat.ambient.y; diff[2] += mat.ambient.z; }
-            const float att = (dot(N, L) > 0 && !shadowed[i]) ? 1.0f : 0.3f;    // rchit:98-133 (specular is zero for illum < 2)
-            for (int k = 0; k < 3; ++k) c[k] = li * att * diff[k];
+            float att = 0.3f, spec[3] = {0.f, 0.f, 0.f};                        // rchit:99-133
+            if (dot(N, L) > 0 && !shadowed[i]) {
+                att = 1.0f;
+                if (mat.illum >= 2) {                                           // computeSpecular, wavefront.glsl:32-48
+                    const float kPi = 3.14159265f, kSh = std::fmax(mat.shininess, 4.0f);
+                    const float kE = (2.0f + kSh) / (2.0f * kPi);
+                    const V3 V = norm(dirs[i] * -1.0f);
+                    const V3 I = L * -1.0f;                                     // reflect(-L, N) = I - 2 dot(N, I) N
+                    const V3 Rr = I - N * (2.0f * dot(N, I));
+                    const float sp = kE * std::pow(std::fmax(dot(V, Rr), 0.0f), kSh);
+                    spec[0] = mat.specular.x * sp; spec[1] = mat.specular.y * sp; spec[2] = mat.specular.z * sp;
+                }
+            }
+            for (int k = 0; k < 3; ++k) c[k] = li * att * (diff[k] + spec[k]);
         }
         for (int k = 0; k < 3; ++k) {
             const float g = std::pow(std::fmin(std::fmax(c[k], 0.f), 1.f), 1.0f / 2.2f);  // post.frag:36
@@ -119,9 +145,10 @@ int render(vx_grid* grid, const std::string& file, uint32_t W, uint32_t H)
 
 template <class T, bool P>
 int run_grid(const std::string& path, float vs, const std::string& dumpFile, const char* label, const std::string& renderFile = "",
-             uint32_t rw = 1280, uint32_t rh = 720)
+             uint32_t rw = 1280, uint32_t rh = 720, bool materials = false, const std::string& matDump = "", const std::string& cameraDump = "")
 {
     VoxelBuilder<T, P> voxelBuilder{std::filesystem::path(path)};
+    voxelBuilder.withMaterials(materials);
     const auto t0 = Clock::now();
     T vox = voxelBuilder.buildVoxelGrid(vs);
     const auto t1 = Clock::now();
@@ -137,7 +164,18 @@ int run_grid(const std::string& path, float vs, const std::string& dumpFile, con
     std::printf("[voxhip] %s: %zu AABBs, %.1f Mvoxels/s build (host wall, incl. launch+sync), %.1f M AABBs/s getAabbs (incl. D2H copy)\n", label,
                 aabbs.size(), cells / sb / 1e6, aabbs.size() / (sa > 0 ? sa : 1e-9) / 1e6);
     dump(dumpFile, aabbs);
-    if (!renderFile.empty()) return render(vox.handle(), renderFile, rw, rh);
+    RenderOpts ro;
+    ro.cameraDump = cameraDump;
+    if (materials) {
+        ro.materials = vox.getMatrials();
+        ro.matIdx = vox.getMatIdx();
+        std::printf("[voxhip] materials: %zu distinct, %zu per-voxel ids\n", ro.materials.size(), ro.matIdx.size());
+        if (!matDump.empty()) {
+            std::ofstream f(matDump, std::ios::binary);
+            f.write(reinterpret_cast<const char*>(ro.matIdx.data()), (std::streamsize)(ro.matIdx.size() * sizeof(int16_t)));
+        }
+    }
+    if (!renderFile.empty()) return render(vox.handle(), renderFile, rw, rh, ro);
     return 0;
 }
 }  // namespace
@@ -145,16 +183,16 @@ int run_grid(const std::string& path, float vs, const std::string& dumpFile, con
 int main(int argc, char** argv)
 {
     if (argc < 3) {  // the reference reads argv[1], argv[2] unchecked (main.cpp:80,163)
-        std::fprintf(stderr, "usage: %s <Path to obj file> <Voxlesize> [--grid bool|aabbstruct|vec|octree] [--parallel] [--dump FILE] [--bench RUNS] [--render FILE.ppm [--size WxH]]\n",
+        std::fprintf(stderr, "usage: %s <Path to obj file> <Voxlesize> [--grid bool|aabbstruct|vec|octree] [--parallel] [--dump FILE] [--bench RUNS] [--render FILE.ppm [--size WxH] [--camera-dump FILE]] [--materials [--dump-materials FILE]]\n",
                      argv[0]);
         return 2;
     }
     const std::string path = argv[1];
     float vs = 0.f;
     try { vs = std::stof(argv[2]); } catch (const std::exception&) { std::fprintf(stderr, "invalid voxel size '%s'\n", argv[2]); return 2; }
-    std::string grid = "bool", dumpFile, renderFile;
+    std::string grid = "bool", dumpFile, renderFile, matDump, cameraDump;
     uint32_t rw = 1280, rh = 720;  // main.cpp:72-73
-    bool parallel = false;
+    bool parallel = false, materials = false;
     long benchRuns = 0;
     for (int i = 3; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--grid") && i + 1 < argc) grid = argv[++i];
@@ -162,6 +200,9 @@ int main(int argc, char** argv)
         else if (!std::strcmp(argv[i], "--dump") && i + 1 < argc) dumpFile = argv[++i];
         else if (!std::strcmp(argv[i], "--bench") && i + 1 < argc) benchRuns = std::atol(argv[++i]);
         else if (!std::strcmp(argv[i], "--render") && i + 1 < argc) renderFile = argv[++i];
+        else if (!std::strcmp(argv[i], "--materials")) materials = true;
+        else if (!std::strcmp(argv[i], "--dump-materials") && i + 1 < argc) matDump = argv[++i];
+        else if (!std::strcmp(argv[i], "--camera-dump") && i + 1 < argc) cameraDump = argv[++i];
         else if (!std::strcmp(argv[i], "--size") && i + 1 < argc) { if (std::sscanf(argv[++i], "%ux%u", &rw, &rh) != 2) { std::fprintf(stderr, "bad --size\n"); return 2; } }
         else { std::fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
     }
@@ -185,7 +226,8 @@ int main(int argc, char** argv)
             dump(dumpFile, aabbs);
             return 0;
         }
-        if (grid == "bool") return parallel ? run_grid<VoxelGridBool, true>(path, vs, dumpFile, "VoxelGridBool", renderFile, rw, rh) : run_grid<VoxelGridBool, false>(path, vs, dumpFile, "VoxelGridBool", renderFile, rw, rh);
+        if (grid == "bool") return parallel ? run_grid<VoxelGridBool, true>(path, vs, dumpFile, "VoxelGridBool", renderFile, rw, rh, materials, matDump, cameraDump)
+                                               : run_grid<VoxelGridBool, false>(path, vs, dumpFile, "VoxelGridBool", renderFile, rw, rh, materials, matDump, cameraDump);
         if (grid == "aabbstruct") return parallel ? run_grid<VoxelGridAABBstruct, true>(path, vs, dumpFile, "VoxelGridAABBstruct") : run_grid<VoxelGridAABBstruct, false>(path, vs, dumpFile, "VoxelGridAABBstruct");
         if (grid == "vec") return parallel ? run_grid<VoxelGridVec, true>(path, vs, dumpFile, "VoxelGridVec") : run_grid<VoxelGridVec, false>(path, vs, dumpFile, "VoxelGridVec");
         std::fprintf(stderr, "unknown grid flavour %s\n", grid.c_str());

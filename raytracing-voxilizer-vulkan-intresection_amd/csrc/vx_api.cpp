@@ -225,6 +225,12 @@ struct vx_mesh {
     std::vector<int32_t> hi;
     std::vector<int32_t> tri_mat;        // material id per triangle (-1 = none); empty: the mesh has no materials
     std::vector<vx_material> materials;  // m_materials of the reference builder (VoxelBuilder.hpp:69)
+    // material VALUES for the voxelizer: the mesh's records de-duplicated by MaterialObj::operator== (value 0 is always the default
+    // MaterialObj{} that faces without usemtl carry, VoxelBuilder.hpp:383) and the value id of every triangle
+    std::vector<vx_material> values;
+    std::vector<int32_t> tri_value;
+    bool values_ready = false;
+    DevBuf btv;  // tri_value on the device
     size_t nv = 0, nt = 0;
     const float* dv = nullptr;
     const int32_t* di = nullptr;
@@ -232,6 +238,32 @@ struct vx_mesh {
     bool borrowed = false;
     bool uploaded = false;
 };
+
+namespace {
+vx_material default_material()  // MaterialObj{} (common/obj_loader.h:32-43)
+{
+    vx_material m;
+    std::memset(&m, 0, sizeof(m));
+    m.ambient[0] = m.ambient[1] = m.ambient[2] = 0.1f;
+    m.diffuse[0] = m.diffuse[1] = 1.0f;
+    m.specular[0] = m.specular[1] = m.specular[2] = 1.0f;
+    m.emission[2] = 0.10f;
+    m.shininess = 0.f;
+    m.ior = 1.0f;
+    m.dissolve = 1.f;
+    m.illum = 0;
+    m.texture_id = -1;
+    return m;
+}
+bool same_material(const vx_material& a, const vx_material& b)  // MaterialObj::operator== (obj_loader.h:45-51): ior and dissolve are not compared
+{
+    for (int k = 0; k < 3; ++k)
+        if (a.ambient[k] != b.ambient[k] || a.diffuse[k] != b.diffuse[k] || a.specular[k] != b.specular[k] || a.transmittance[k] != b.transmittance[k] ||
+            a.emission[k] != b.emission[k])
+            return false;
+    return a.shininess == b.shininess && a.illum == b.illum && a.texture_id == b.texture_id;
+}
+}  // namespace
 
 struct vx_grid {
     int device = 0;
@@ -241,7 +273,10 @@ struct vx_grid {
     float bbmin[3] = {0, 0, 0}, bbmax[3] = {0, 0, 0}, bbc[3] = {0, 0, 0};
     uint64_t triangles = 0;
     uint32_t cdim[3] = {0, 0, 0}, c2dim[3] = {0, 0, 0};
-    DevBuf words, cwords, c2words, bricks, idxtmp, ttmp, camera, wprefix, recs, units, ubase, btri, umask, hbase, scantmp, small, vec;
+    DevBuf words, cwords, c2words, bricks, idxtmp, ttmp, camera, wprefix, recs, units, ubase, btri, umask, hbase, scantmp, small, vec, matids, mattmp;
+    std::vector<vx_material> materials;  // m_materials: distinct values in first-use order (VX_VOXELIZE_MATERIALS builds only)
+    uint64_t mat_count = 0;              // entries of matids
+    bool has_materials = false;
     bool coarse_valid = false, prefix_valid = false /*word_prefix queued or done*/, occupied_known = false, counts_valid = true;
     uint64_t occupied = 0, set_calls = 0, host_set_calls = 0;
     uint64_t vec_count = 0;
@@ -249,18 +284,18 @@ struct vx_grid {
     void set_dev(int d)
     {
         device = d;
-        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &idxtmp, &ttmp, &camera, &wprefix, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec}) b->dev = d;
+        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &idxtmp, &ttmp, &camera, &wprefix, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec, &matids, &mattmp}) b->dev = d;
     }
     // the stream this handle queues work on; the pool orders the reuse of released blocks by it
     void set_stream(hipStream_t st)
     {
         if (st != stream && words.p) (void)hipStreamSynchronize(stream);  // work queued on the old stream must not outlive the switch
         stream = st;
-        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &idxtmp, &ttmp, &camera, &wprefix, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec}) b->stream = st;
+        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &idxtmp, &ttmp, &camera, &wprefix, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec, &matids, &mattmp}) b->stream = st;
     }
     void release_all()
     {
-        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &idxtmp, &ttmp, &camera, &wprefix, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec}) b->release();
+        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &idxtmp, &ttmp, &camera, &wprefix, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec, &matids, &mattmp}) b->release();
         if (mail) (void)hipHostFree(mail);
         mail = nullptr;
     }
@@ -294,6 +329,42 @@ vx_status mesh_to_device(vx_mesh* m)
     m->dv = m->bv.as<float>();
     m->di = m->bi.as<int32_t>();
     m->uploaded = true;
+    return VX_OK;
+}
+
+// material values of a mesh (host) and their per-triangle ids on the device
+vx_status mesh_material_values(vx_mesh* m)
+{
+    if (!m->values_ready) {
+        if (m->borrowed && !m->tri_mat.empty() && m->tri_mat.size() != m->nt) return fail(VX_ERR_INVALID_ARG, "material ids do not match the triangle count");
+        m->values.clear();
+        m->values.push_back(default_material());
+        std::vector<int32_t> rec_value(m->materials.size(), 0);
+        for (size_t i = 0; i < m->materials.size(); ++i) {
+            // VoxelBuilder copies the record into a fresh MaterialObj (VoxelBuilder.hpp:383-394): textureID stays -1
+            vx_material v = m->materials[i];
+            v.texture_id = -1;
+            int32_t id = -1;
+            for (size_t k = 0; k < m->values.size(); ++k)
+                if (same_material(m->values[k], v)) { id = (int32_t)k; break; }
+            if (id < 0) { m->values.push_back(v); id = (int32_t)m->values.size() - 1; }
+            rec_value[i] = id;
+        }
+        if (m->values.size() > 32767) return fail(VX_ERR_CAPACITY, "more than 32767 distinct materials: per-voxel ids are int16 (voxelgrid.hpp:29)");
+        m->tri_value.assign(m->nt, 0);
+        if (!m->tri_mat.empty())
+            for (size_t t = 0; t < m->nt; ++t) {
+                const int32_t id = m->tri_mat[t];
+                m->tri_value[t] = (id >= 0 && (size_t)id < rec_value.size()) ? rec_value[(size_t)id] : 0;  // VoxelBuilder.hpp:384: out-of-range ids keep the default
+            }
+        m->values_ready = true;
+        m->btv.release();
+    }
+    if (!m->btv.p && m->nt) {
+        m->btv.dev = m->device;
+        VX_HIP(m->btv.ensure(m->nt * 4 + 16));
+        VX_HIP(hipMemcpy(m->btv.p, m->tri_value.data(), m->nt * 4, hipMemcpyHostToDevice));
+    }
     return VX_OK;
 }
 
@@ -582,19 +653,21 @@ vx_status vx_mesh_set_materials(vx_mesh* m, const vx_material* mats, size_t n, c
             if (ids[t] < -1 || (ids[t] >= 0 && (size_t)ids[t] >= n)) return fail(VX_ERR_INVALID_ARG, "material id out of range");
     m->materials.assign(mats, mats + n);
     if (ids && n) m->tri_mat.assign(ids, ids + m->nt); else m->tri_mat.clear();
+    m->values_ready = false;
     return VX_OK;
 }
 
 void vx_mesh_free(vx_mesh* m)
 {
     if (!m) return;
-    if (m->uploaded) {
+    if (m->uploaded || m->btv.p) {
         // grids on any stream may still be reading the vertex / index arrays: wait for the device before the blocks go back
         DeviceGuard dg(m->device);
         (void)hipDeviceSynchronize();
     }
     m->bv.release(/*in_flight=*/false);
     m->bi.release(/*in_flight=*/false);
+    m->btv.release(/*in_flight=*/false);
     delete m;
 }
 
@@ -613,6 +686,12 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
     g->set_stream((hipStream_t)o.stream);
     hipStream_t s = g->stream;
     if (o.sat_variant != 0 && o.sat_variant != 1) return fail(VX_ERR_INVALID_ARG, "sat_variant must be 0 or 1");
+    const bool want_mat = (o.flags & VX_VOXELIZE_MATERIALS) != 0;
+    if (want_mat && (o.word_begin || o.word_end || o.tri_begin || o.tri_end)) return fail(VX_ERR_UNSUPPORTED, "VX_VOXELIZE_MATERIALS is not available for sharded builds");
+    if (want_mat) VX_TRY(mesh_material_values(mesh));
+    g->has_materials = false;
+    g->materials.clear();
+    g->mat_count = 0;
 
     VX_HIP(ensure_small(g->small));
     if (!g->mail) VX_HIP(mail_alloc(&g->mail));
@@ -667,6 +746,7 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
     g->triangles = te - tb;
     if (ntri == 0 || nvox == 0 || wb == we) {
         if (!mask_is_clear) VX_HIP(hipMemsetAsync(g->words.p, 0, mask_bytes, s));
+        g->has_materials = want_mat;
         return VX_OK;
     }
 
@@ -686,9 +766,9 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
         VX_HIP(hipMemsetAsync(g->words.p, 0, mask_bytes, s));
         VX_TRY(setup_finish(ntri, g->ubase, g->btri, g->mail, s, &U));
     }
-    if (U == 0) return VX_OK;
+    if (U == 0) { g->has_materials = want_mat; return VX_OK; }
     uint32_t* umask = nullptr;
-    if (g->kind == VX_GRID_VEC) {
+    if (g->kind == VX_GRID_VEC || want_mat) {
         VX_HIP(g->umask.ensure((size_t)(U + 1) * 4));
         umask = g->umask.as<uint32_t>();
     }
@@ -732,6 +812,45 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
                                   g->hbase.as<uint32_t>(), g->vec.as<vx_aabb>(), nullptr, s);
         }
         g->vec_count = hits;
+    }
+    if (want_mat) {
+        // ---- per-voxel material ids (see k_mat_last): needs the word prefix (queued above for an unsharded build) and, for the Vec
+        // flavour, the hit bases; the order in which materials are first used is settled on the host from one byte per triangle
+        bool pending = false;
+        VX_TRY(prefix_launch(g, &pending));
+        VX_TRY(prefix_finish(g, pending));
+        const uint64_t nids = g->kind == VX_GRID_VEC ? g->vec_count : g->occupied;
+        const size_t tmp_bytes = (g->kind == VX_GRID_VEC ? 0 : (size_t)g->occupied * 4) + (size_t)ntri + 64 + mesh->values.size() * 2 + 64;
+        VX_HIP(g->mattmp.ensure(tmp_bytes));
+        uint8_t* base = g->mattmp.as<uint8_t>();
+        uint32_t* last_tri = g->kind == VX_GRID_VEC ? nullptr : reinterpret_cast<uint32_t*>(base);
+        uint8_t* tri_hit = base + (g->kind == VX_GRID_VEC ? 0 : (size_t)g->occupied * 4);
+        int16_t* value_index = reinterpret_cast<int16_t*>(tri_hit + (((size_t)ntri + 63) & ~(size_t)63));
+        VX_HIP(hipMemsetAsync(base, 0, (size_t)(tri_hit - base) + ntri, s));
+        vx::launch_mat_last(g->recs.as<vx::TriRec>(), g->ubase.as<uint32_t>(), g->btri.as<uint32_t>(), ntri, g->g, umask, g->words.as<uint32_t>(),
+                            g->wprefix.as<uint32_t>(), last_tri, tri_hit, s);
+        std::vector<uint8_t> hit(ntri);
+        VX_HIP(hipMemcpyAsync(hit.data(), tri_hit, ntri, hipMemcpyDeviceToHost, s));
+        VX_HIP(hipStreamSynchronize(s));
+        // addMatrialIfNeeded (voxelgrid.hpp:102-114): a value gets the next index when the first setVoxel call carrying it arrives
+        std::vector<int16_t> vindex(mesh->values.size(), (int16_t)-1);
+        const int32_t* tv = mesh->tri_value.data() + tb;
+        for (uint32_t t = 0; t < ntri; ++t) {
+            if (!hit[t] || vindex[(size_t)tv[t]] >= 0) continue;
+            vindex[(size_t)tv[t]] = (int16_t)g->materials.size();
+            g->materials.push_back(mesh->values[(size_t)tv[t]]);
+        }
+        VX_HIP(hipMemcpyAsync(value_index, vindex.data(), vindex.size() * 2, hipMemcpyHostToDevice, s));
+        VX_HIP(g->matids.ensure((size_t)nids * 2 + 16));
+        const int32_t* dtv = mesh->btv.as<int32_t>() + tb;
+        if (g->kind == VX_GRID_VEC)
+            vx::launch_mat_ids_calls(g->recs.as<vx::TriRec>(), g->ubase.as<uint32_t>(), g->btri.as<uint32_t>(), ntri, umask, g->hbase.as<uint32_t>(), dtv, value_index,
+                                     g->matids.as<int16_t>(), s);
+        else
+            vx::launch_mat_ids(last_tri, nids, dtv, value_index, g->matids.as<int16_t>(), s);
+        VX_HIP(hipStreamSynchronize(s));  // vindex lives on this stack frame
+        g->mat_count = nids;
+        g->has_materials = true;
     }
     VX_HIP(hipGetLastError());
     return VX_OK;
@@ -828,6 +947,7 @@ vx_status vx_grid_set_voxel(vx_grid* g, uint64_t x, uint64_t y, uint64_t z)
     g->host_set_calls++;
     g->set_calls++;
     g->coarse_valid = g->prefix_valid = g->occupied_known = false;
+    g->has_materials = false;  // ids are per box of the list: a host-side setVoxel (default material, not recorded) invalidates them
     return VX_OK;
 }
 
@@ -940,6 +1060,31 @@ vx_status vx_grid_aabbs(const vx_grid* gc, vx_aabb* host_out, uint64_t cap, uint
     VX_HIP(e);
     return VX_OK;
 }
+
+vx_status vx_grid_materials(const vx_grid* g, vx_material* out, uint64_t cap, uint64_t* count)
+{
+    if (!g || (!out && cap)) return fail(VX_ERR_INVALID_ARG, "null argument");
+    const uint64_t n = g->has_materials ? g->materials.size() : 0;
+    if (count) *count = n;
+    const uint64_t m = cap < n ? cap : n;
+    if (m) std::memcpy(out, g->materials.data(), (size_t)m * sizeof(vx_material));
+    return VX_OK;
+}
+
+vx_status vx_grid_material_ids(const vx_grid* g, int16_t* out, uint64_t cap, uint64_t* count)
+{
+    if (!g || (!out && cap)) return fail(VX_ERR_INVALID_ARG, "null argument");
+    const uint64_t n = g->has_materials ? g->mat_count : 0;
+    if (count) *count = n;
+    const uint64_t m = cap < n ? cap : n;
+    if (!m) return VX_OK;
+    DeviceGuard dg(g->device);
+    VX_HIP(hipMemcpyAsync(out, g->matids.p, (size_t)m * 2, hipMemcpyDeviceToHost, g->stream));
+    VX_HIP(hipStreamSynchronize(g->stream));
+    return VX_OK;
+}
+
+const int16_t* vx_grid_material_ids_device(const vx_grid* g) { return (g && g->has_materials && g->mat_count) ? g->matids.as<int16_t>() : nullptr; }
 
 void vx_grid_free(vx_grid* g)
 {

@@ -76,6 +76,15 @@ void launch_voxelize(const TriRec* recs, const uint32_t* unit_base, const uint32
 void launch_emit_units(const TriRec* recs, const uint32_t* unit_base, const uint32_t* block_tri, uint32_t ntri, const GridParams& g,
                        const uint32_t* unit_mask, const uint32_t* hit_base, vx_aabb* aabbs, uint64_t* morton, hipStream_t s, uint64_t cap = ~0ull);
 
+// Per-voxel material ids (the reference's commented-out addMatrialIfNeeded plumbing): pass 1 = last triangle per occupied voxel
+// (last_tri[rank], zeroed by the caller; may be null for the Vec flavour) + tri_hit[t] = 1 for triangles that set a voxel (zeroed by
+// the caller); pass 2 = triangle -> material value -> index of first use.
+void launch_mat_last(const TriRec* recs, const uint32_t* unit_base, const uint32_t* block_tri, uint32_t ntri, const GridParams& g, const uint32_t* unit_mask,
+                     const uint32_t* words, const uint32_t* word_prefix, uint32_t* last_tri, uint8_t* tri_hit, hipStream_t s);
+void launch_mat_ids(const uint32_t* last_tri, uint64_t n, const int32_t* tri_value, const int16_t* value_index, int16_t* out, hipStream_t s);
+void launch_mat_ids_calls(const TriRec* recs, const uint32_t* unit_base, const uint32_t* block_tri, uint32_t ntri, const uint32_t* unit_mask,
+                          const uint32_t* hit_base, const int32_t* tri_value, const int16_t* value_index, int16_t* out, hipStream_t s);
+
 // K4: bitmask -> ordered AABB list (word_prefix = exclusive scan of popcounts, nwords+1 entries)
 void launch_emit_bool_aabbs(const uint32_t* words, const uint32_t* word_prefix, const GridParams& g, vx_aabb* out,
                             uint64_t capacity, hipStream_t s);

@@ -879,6 +879,82 @@ void launch_emit_morton_aabbs(const uint64_t* items, uint64_t n, const float roo
                        root_min[2], vs, out);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Per-voxel material ids: the plumbing the reference keeps commented out (VoxelBuilder.hpp:375-395 -> setVoxel ->
+// addMatrialIfNeeded, voxelgrid.hpp:102-114, call sites voxelgridBool.cpp:64, voxelgridAABBstruct.cpp:31,
+// voxelgridVecEncoding.cpp:27).  m_matIdx[idx] is overwritten by every setVoxel call on the voxel, so what survives is the
+// material of the LAST call = of the highest-numbered triangle that hits the voxel (calls run in triangle order and a triangle
+// sets a voxel at most once).  Pass 1 takes that maximum per occupied voxel (addressed by its rank in the ascending AABB
+// list) and marks the triangles that hit anything (the order in which materials are first used defines their index);
+// pass 2 maps triangle -> material value -> index.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mat_last(const TriRec* __restrict__ recs, const uint32_t* __restrict__ unit_base, const uint32_t* __restrict__ block_tri,
+                                                  uint32_t ntri, GridParams g, const uint32_t* __restrict__ unit_mask, const uint32_t* __restrict__ words,
+                                                  const uint32_t* __restrict__ word_prefix, uint32_t* __restrict__ last_tri /*per occupied voxel, 0 = none yet*/,
+                                                  uint8_t* __restrict__ tri_hit)
+{
+    __shared__ UnitStage stage;
+    for_each_unit(recs, unit_base, block_tri, ntri, stage, [&](uint32_t u, uint32_t t, const TriRec& r, uint32_t rel) {
+        uint32_t mask = unit_mask[u];
+        if (!mask) return;
+        tri_hit[t] = 1;
+        if (!last_tri) return;
+        const Unit w = decode_unit(r, t, rel);
+        const uint64_t row = (uint64_t)g.dim[0] * ((uint64_t)w.y + (uint64_t)g.dim[1] * w.z);
+        while (mask) {
+            const uint32_t b = __ffs(mask) - 1;
+            mask &= mask - 1;
+            const uint64_t i = row + w.xseg + b;
+            const uint64_t wi = i >> 5;
+            const uint32_t rank = word_prefix[wi] + __popc(words[wi] & ((1u << (i & 31u)) - 1u));
+            atomicMax(&last_tri[rank], t + 1u);
+        }
+    });
+}
+
+// Bool / AABBstruct: one id per occupied voxel, in ascending voxel order (== the order of getAabbs and of VoxelGrid::getMatIdx)
+__global__ __launch_bounds__(256) void k_mat_ids(const uint32_t* __restrict__ last_tri, uint64_t n, const int32_t* __restrict__ tri_value,
+                                                 const int16_t* __restrict__ value_index, int16_t* __restrict__ out)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u) {
+        const uint32_t lt = last_tri[i];
+        out[i] = lt ? value_index[tri_value[lt - 1u]] : (int16_t)-1;
+    }
+}
+
+// Vec: addMatrialIfNeeded(m_voxelSet, material) -- one id per setVoxel call, in call order (the order of the Aabb list)
+__global__ __launch_bounds__(256) void k_mat_ids_calls(const TriRec* __restrict__ recs, const uint32_t* __restrict__ unit_base, const uint32_t* __restrict__ block_tri,
+                                                       uint32_t ntri, const uint32_t* __restrict__ unit_mask, const uint32_t* __restrict__ hit_base,
+                                                       const int32_t* __restrict__ tri_value, const int16_t* __restrict__ value_index, int16_t* __restrict__ out)
+{
+    __shared__ UnitStage stage;
+    for_each_unit(recs, unit_base, block_tri, ntri, stage, [&](uint32_t u, uint32_t t, const TriRec&, uint32_t) {
+        const uint32_t n = __popc(unit_mask[u]);
+        if (!n) return;
+        const int16_t id = value_index[tri_value[t]];
+        const uint32_t off = hit_base[u];
+        for (uint32_t k = 0; k < n; ++k) out[off + k] = id;
+    });
+}
+
+void launch_mat_last(const TriRec* recs, const uint32_t* unit_base, const uint32_t* block_tri, uint32_t ntri, const GridParams& g, const uint32_t* unit_mask,
+                     const uint32_t* words, const uint32_t* word_prefix, uint32_t* last_tri, uint8_t* tri_hit, hipStream_t s)
+{
+    if (!ntri) return;
+    VX_KL(k_mat_last, dim3(kMaxBlocks), dim3(256), 0, s, recs, unit_base, block_tri, ntri, g, unit_mask, words, word_prefix, last_tri, tri_hit);
+}
+void launch_mat_ids(const uint32_t* last_tri, uint64_t n, const int32_t* tri_value, const int16_t* value_index, int16_t* out, hipStream_t s)
+{
+    if (!n) return;
+    VX_KL(k_mat_ids, dim3(grid_for(n, 256, kMaxBlocks)), dim3(256), 0, s, last_tri, n, tri_value, value_index, out);
+}
+void launch_mat_ids_calls(const TriRec* recs, const uint32_t* unit_base, const uint32_t* block_tri, uint32_t ntri, const uint32_t* unit_mask,
+                          const uint32_t* hit_base, const int32_t* tri_value, const int16_t* value_index, int16_t* out, hipStream_t s)
+{
+    if (!ntri) return;
+    VX_KL(k_mat_ids_calls, dim3(kMaxBlocks), dim3(256), 0, s, recs, unit_base, block_tri, ntri, unit_mask, hit_base, tri_value, value_index, out);
+}
+
 __global__ void k_set_bit(uint32_t* words, uint64_t idx) { atomicOr(&words[idx >> 5], 1u << (idx & 31)); }
 void launch_set_bit(uint32_t* words, uint64_t idx, hipStream_t s) { VX_KL(k_set_bit, dim3(1), dim3(1), 0, s, words, idx); }
 

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(HERE, "libvoxhip.so")
 
 VX_OK = 0
 GRID_BOOL, GRID_AABBSTRUCT, GRID_VEC = 0, 1, 2
+VOXELIZE_MATERIALS = 1
 STATUS_NAMES = {0: "VX_OK", 1: "VX_ERR_INVALID_ARG", 2: "VX_ERR_PATH", 3: "VX_ERR_PARSE", 4: "VX_ERR_OUT_OF_BOUNDS",
                 5: "VX_ERR_MORTON_BITS", 6: "VX_ERR_NO_DEVICE", 7: "VX_ERR_HIP", 8: "VX_ERR_CAPACITY", 9: "VX_ERR_UNSUPPORTED"}
 
@@ -31,7 +32,7 @@ class GridDesc(C.Structure):
 
 
 class VoxelizeOpts(C.Structure):
-    _fields_ = [("sat_variant", C.c_int32), ("reserved", C.c_int32), ("word_begin", C.c_uint64), ("word_end", C.c_uint64),
+    _fields_ = [("sat_variant", C.c_int32), ("flags", C.c_int32), ("word_begin", C.c_uint64), ("word_end", C.c_uint64),
                 ("tri_begin", C.c_uint64), ("tri_end", C.c_uint64), ("stream", C.c_void_p)]
 
 
@@ -58,7 +59,7 @@ SYMBOLS = [
     "vx_voxelize", "vx_voxelize_into",
     "vx_grid_create", "vx_grid_describe", "vx_grid_set_voxel", "vx_grid_test_voxel", "vx_grid_coords", "vx_grid_bytes",
     "vx_grid_bitmask", "vx_grid_bitmask_device", "vx_grid_bitmask_device_mut", "vx_grid_refresh", "vx_grid_aabbs",
-    "vx_grid_aabbs_device", "vx_grid_free",
+    "vx_grid_aabbs_device", "vx_grid_materials", "vx_grid_material_ids", "vx_grid_material_ids_device", "vx_grid_free",
     "vx_octree_build", "vx_octree_num_items", "vx_octree_num_nodes", "vx_octree_bytes", "vx_octree_items", "vx_octree_nodes",
     "vx_octree_root_bounds", "vx_octree_aabbs", "vx_octree_aabbs_device", "vx_octree_free",
     "vx_trace", "vx_trace_device", "vx_trace_primary_device", "vx_trace_ex", "vx_trace_ex_device",
@@ -144,6 +145,10 @@ def lib():
     L.vx_grid_refresh.argtypes = [vp]
     L.vx_grid_aabbs.argtypes = [vp, vp, C.c_uint64, u64p]
     L.vx_grid_aabbs_device.argtypes = [vp, vp, C.c_uint64, u64p]
+    L.vx_grid_materials.argtypes = [vp, vp, C.c_uint64, u64p]
+    L.vx_grid_material_ids.argtypes = [vp, vp, C.c_uint64, u64p]
+    L.vx_grid_material_ids_device.argtypes = [vp]
+    L.vx_grid_material_ids_device.restype = vp
     L.vx_grid_free.argtypes = [vp]
     L.vx_grid_free.restype = None
     L.vx_octree_build.argtypes = [vp, C.c_float, C.c_uint64, vp, C.POINTER(vp)]
@@ -304,9 +309,10 @@ class Grid:
         self.h = handle
 
     @classmethod
-    def voxelize(cls, mesh, voxel_size, kind=GRID_BOOL, sat_variant=0, words=None, tris=None, stream=None):
+    def voxelize(cls, mesh, voxel_size, kind=GRID_BOOL, sat_variant=0, words=None, tris=None, stream=None, materials=False):
         o = VoxelizeOpts()
         o.sat_variant = sat_variant
+        o.flags = VOXELIZE_MATERIALS if materials else 0
         if words is not None:
             o.word_begin, o.word_end = words
         if tris is not None:
@@ -316,9 +322,10 @@ class Grid:
         _check(lib().vx_voxelize(mesh.h, np.float32(voxel_size), kind, C.byref(o), C.byref(h)))
         return cls(h)
 
-    def revoxelize(self, mesh, voxel_size, sat_variant=0, words=None, tris=None, stream=None):
+    def revoxelize(self, mesh, voxel_size, sat_variant=0, words=None, tris=None, stream=None, materials=False):
         o = VoxelizeOpts()
         o.sat_variant = sat_variant
+        o.flags = VOXELIZE_MATERIALS if materials else 0
         if words is not None:
             o.word_begin, o.word_end = words
         if tris is not None:
@@ -376,6 +383,19 @@ class Grid:
         if n.value:
             _check(lib().vx_grid_aabbs(self.h, out.ctypes.data, n.value, C.byref(n)))
         return out
+
+    def materials(self):
+        """(getMatrials() as MATERIAL records, getMatIdx() as int16[]) -- empty unless built with materials=True."""
+        n = C.c_uint64()
+        _check(lib().vx_grid_materials(self.h, None, 0, C.byref(n)))
+        recs = np.zeros(n.value, dtype=MATERIAL)
+        if n.value:
+            _check(lib().vx_grid_materials(self.h, recs.ctypes.data, n.value, C.byref(n)))
+        _check(lib().vx_grid_material_ids(self.h, None, 0, C.byref(n)))
+        ids = np.zeros(n.value, dtype=np.int16)
+        if n.value:
+            _check(lib().vx_grid_material_ids(self.h, ids.ctypes.data, n.value, C.byref(n)))
+        return recs, ids
 
     def aabbs_device(self, dev_ptr, capacity):
         n = C.c_uint64()

@@ -99,3 +99,57 @@ def test_cli_render(gpu, tmp_path):
     assert abs(int((~is_bg).sum()) - int((tt > 0).sum())) <= 2     # the two camera set-ups differ in the last float bits
     shades = np.unique(img[~is_bg][:, 0])
     assert len(shades) >= 2 and img[~is_bg][:, 2].max() == 0        # yellow default material: blue channel stays 0
+
+
+def test_cli_render_matches_oracle_shade(gpu, tmp_path):
+    """--render (+ --materials) per pixel against the oracle's restatement of the reference's shaders (rgen, rint, rchit2, rmiss,
+    post.frag) on the oracle's own boxes and material ids: within 1 LSB, except where a silhouette or shadow edge falls between
+    the two ray set-ups' last float bits (a handful of pixels)."""
+    v, t = vx_scenes.rotated_cube(half=1.0, offset=(0.0, 1.0, 0.0))
+    (tmp_path / "m.mtl").write_text("newmtl shiny\nKa 0.05 0.05 0.1\nKd 0.2 0.4 0.9\nKs 0.9 0.9 0.9\nNs 48\nillum 2\n"
+                                    "newmtl matte\nKa 0.1 0.0 0.0\nKd 0.9 0.3 0.2\nillum 1\n")
+    obj = tmp_path / "c.obj"
+    lines = ["mtllib m.mtl"] + ["v %.9g %.9g %.9g" % tuple(p) for p in v.tolist()]
+    ids = []
+    for k, tri in enumerate(t.tolist()):
+        mid = [-1, 0, 1][(k // 2) % 3]
+        lines.append({-1: "usemtl none_such", 0: "usemtl shiny", 1: "usemtl matte"}[mid])
+        lines.append("f %d %d %d" % (tri[0] + 1, tri[1] + 1, tri[2] + 1))
+        ids.append(mid)
+    obj.write_text("\n".join(lines) + "\n")
+    W, H = 240, 135
+    vs = np.float32(0.05)
+    ow, _, gi = oracle.build_bool(v, t, vs)
+    oa = oracle.bool_aabbs(ow, gi, vs)
+    for with_mat in (False, True):
+        ppm, cam, md = tmp_path / "o.ppm", tmp_path / "cam.bin", tmp_path / "mat.bin"
+        cmd = [os.path.join(PKG, "voxilizer"), str(obj), "0.05", "--render", str(ppm), "--size", "%dx%d" % (W, H), "--camera-dump", str(cam)]
+        if with_mat:
+            cmd += ["--materials", "--dump-materials", str(md)]
+        r = run(cmd)
+        assert r.returncode == 0, r.stdout
+        raw = open(ppm, "rb").read()
+        hdr = b"P6\n%d %d\n255\n" % (W, H)
+        assert raw.startswith(hdr)
+        img = np.frombuffer(raw[len(hdr):], np.uint8).reshape(H, W, 3)
+        cm = np.fromfile(cam, np.float32)
+        vi, pi = cm[:16], cm[16:]
+        mats, midx = None, None
+        if with_mat:
+            # value ids as the library forms them: 0 = MaterialObj{}, 1 = shiny, 2 = matte; faces with an unknown usemtl carry the default
+            tv = np.array([0 if i < 0 else i + 1 for i in ids], np.int32)
+            midx, order = oracle.material_ids(v, t, vs, tv, 3)
+            assert np.array_equal(np.fromfile(md, np.int16), midx)
+            recs = np.zeros(3, dtype=gpu.MATERIAL)
+            recs[0] = (tuple([0.1] * 3), (1, 1, 0), (1, 1, 1), (0, 0, 0), (0, 0, 0.1), 0, 1, 1, 0, -1)
+            recs[1] = ((0.05, 0.05, 0.1), (0.2, 0.4, 0.9), (0.9, 0.9, 0.9), (0, 0, 0), (0, 0, 0), 48, 1, 1, 2, -1)
+            recs[2] = ((0.1, 0, 0), (0.9, 0.3, 0.2), (0, 0, 0), (0, 0, 0), (0, 0, 0), 1, 1, 1, 1, -1)
+            mats = recs[order]
+        exp = oracle.shade_image(oa, vi, pi, W, H, materials=mats, mat_idx=midx)
+        diff = np.abs(img.astype(np.int16) - exp.astype(np.int16)).max(axis=2)
+        assert (diff <= 1).mean() > 0.997, "materials=%s: %d of %d pixels differ by more than 1 LSB" % (with_mat, int((diff > 1).sum()), W * H)
+        bg = int(round((0.8 ** (1 / 2.2)) * 255))
+        hit = ~np.all(exp == bg, axis=2)
+        assert 0.02 < hit.mean() < 0.9
+        if with_mat:
+            assert len(np.unique(exp[hit].reshape(-1, 3), axis=0)) > 8      # several materials, lit / shadowed / specular shades

@@ -582,3 +582,83 @@ def test_c4_atrium_1024_eight_shards(gpu):
         total_calls += g.describe()["set_calls"]
     assert np.array_equal(acc, fw)
     assert total_calls >= calls                         # hits of words split between two shards are counted by both owners' halves only once each
+
+
+# ---------------------------------------------------------------------------------------------- per-voxel materials
+def _material_scene(name, nmat, seed):
+    """Scene + `nmat` material records, two of them equal under MaterialObj::operator== (they differ only in ior / dissolve), and a
+    per-triangle id pattern with runs, interleaving and some faces without a material (-1)."""
+    v, t = vx_scenes.scene(name)
+    rng = np.random.default_rng(seed)
+    recs = np.zeros(nmat, dtype=np.dtype([("ambient", np.float32, 3), ("diffuse", np.float32, 3), ("specular", np.float32, 3), ("transmittance", np.float32, 3),
+                                          ("emission", np.float32, 3), ("shininess", np.float32), ("ior", np.float32), ("dissolve", np.float32),
+                                          ("illum", np.int32), ("texture_id", np.int32)]))
+    for k in range(nmat):
+        recs[k]["diffuse"] = rng.uniform(0, 1, 3)
+        recs[k]["ambient"] = rng.uniform(0, 0.2, 3)
+        recs[k]["specular"] = 0.5
+        recs[k]["shininess"] = 10 + k
+        recs[k]["ior"], recs[k]["dissolve"], recs[k]["illum"], recs[k]["texture_id"] = 1.0, 1.0, 2, -1
+    if nmat >= 3:
+        recs[2] = recs[0]
+        recs[2]["ior"], recs[2]["dissolve"] = 1.5, 0.5          # == recs[0] for operator== (ior and dissolve are not compared)
+    n = len(t)
+    ids = (np.arange(n) // max(1, n // (3 * nmat))) % nmat
+    ids[rng.integers(0, n, n // 7)] = rng.integers(0, nmat, n // 7)
+    ids[rng.integers(0, n, n // 11)] = -1
+    ids[: n // 50] = -1 if seed % 2 else nmat - 1                # which material is met FIRST decides the index order
+    return v, t, recs, ids.astype(np.int32)
+
+
+def _value_ids(recs, ids):
+    """Value ids as the library forms them: 0 = MaterialObj{}, then the records de-duplicated by operator== in record order."""
+    keyf = lambda r: (tuple(r["ambient"]), tuple(r["diffuse"]), tuple(r["specular"]), tuple(r["transmittance"]), tuple(r["emission"]), float(r["shininess"]), int(r["illum"]), -1)
+    default = ((np.float32(0.1),) * 3, (np.float32(1), np.float32(1), np.float32(0)), (np.float32(1),) * 3, (np.float32(0),) * 3,
+               (np.float32(0), np.float32(0), np.float32(0.1)), 0.0, 0, -1)
+    keys, rec_value, values = [default], [], [None]
+    for r in recs:
+        k = keyf(r)
+        if k not in keys:
+            keys.append(k)
+            values.append(r)
+        rec_value.append(keys.index(k))
+    tv = np.array([rec_value[i] if i >= 0 else 0 for i in ids], np.int32)
+    return tv, len(keys), values
+
+
+@pytest.mark.parametrize("name,vs,nmat,seed", [("cube", 0.25, 3, 1), ("rotcube", 0.09, 4, 2), ("adversarial", 0.0625, 5, 3), ("soup2000", 0.02, 6, 4), ("blob70k", 2.0 / 64, 4, 5)])
+def test_material_ids(gpu, name, vs, nmat, seed):
+    """VX_VOXELIZE_MATERIALS: getMatrials() / getMatIdx() as the reference's commented-out plumbing would fill them
+    (VoxelBuilder.hpp:375-395, voxelgrid.hpp:102-114): last setVoxel call wins per voxel (Bool / AABBstruct), one id per call (Vec),
+    materials indexed in the order they are first used, equal materials (operator==) share an index."""
+    v, t, recs, ids = _material_scene(name, nmat, seed)
+    vs = np.float32(vs)
+    mesh = gpu.Mesh.from_arrays(v, t)
+    mesh.set_materials(recs, ids)
+    tv, nvalues, values = _value_ids(recs, ids)
+    for kind in (gpu.GRID_BOOL, gpu.GRID_AABBSTRUCT, gpu.GRID_VEC):
+        g = gpu.Grid.voxelize(mesh, vs, kind, materials=True)
+        mats, mid = g.materials()
+        per_call = kind == gpu.GRID_VEC
+        calls = g.describe()["set_calls"]
+        oids, order = oracle.material_ids(v, t, vs, tv, nvalues, per_call=per_call, ncalls=calls)
+        assert np.array_equal(mid, oids), "kind %d: material ids differ" % kind
+        assert len(mid) == (calls if per_call else g.describe()["occupied"]) == len(g.aabbs())
+        assert len(mats) == len(order)
+        for k, vid in enumerate(order):
+            exp = values[vid]
+            if exp is None:   # MaterialObj{}
+                assert mats[k]["diffuse"].tolist() == [1, 1, 0] and mats[k]["ambient"].tolist() == [np.float32(0.1)] * 3 and mats[k]["shininess"] == 0 and mats[k]["illum"] == 0
+            else:
+                assert mats[k]["diffuse"].tolist() == exp["diffuse"].tolist() and mats[k]["shininess"] == exp["shininess"] and mats[k]["ior"] == exp["ior"]
+        assert np.array_equal(g.bitmask(), gpu.Grid.voxelize(mesh, vs, gpu.GRID_BOOL).bitmask())   # occupancy is unaffected
+    # without the flag: the reference as it runs today -- nothing is recorded
+    mats, mid = gpu.Grid.voxelize(mesh, vs).materials()
+    assert len(mats) == 0 and len(mid) == 0
+    # a mesh without materials: every face carries MaterialObj{}
+    plain = gpu.Mesh.from_arrays(v, t)
+    g = gpu.Grid.voxelize(plain, vs, materials=True)
+    mats, mid = g.materials()
+    assert (len(mats) == 1 and not mid.any() and len(mid) == g.describe()["occupied"]) or g.describe()["occupied"] == 0
+    with pytest.raises(gpu.VxError):
+        gpu.Grid.voxelize(mesh, vs, words=(0, 1), materials=True)
