@@ -133,6 +133,17 @@ vx_status vx_voxelize(const vx_mesh* mesh, float voxel_size, vx_grid_kind kind, 
 /* same, re-using an existing grid handle's device buffers (steady-state loops; no allocation when sizes repeat) */
 vx_status vx_voxelize_into(const vx_mesh* mesh, float voxel_size, const vx_voxelize_opts* opts, vx_grid* grid);
 
+/* ---- the same build spread over several GPUs of one process (the call site on a multi-GPU node: hello_vulkan.cpp:677-683).
+ * Device k of `devices` voxelizes the bitmask words vx_shard_words(num_words, k, num_devices) of the SAME grid -- contributions are
+ * word-disjoint, so their OR is their concatenation -- and the shards travel over xGMI as peer copies (hipMemcpyPeerAsync: one
+ * slab per peer link, no collective library needed inside one process; the one-process-per-GPU form of the same exchange is the
+ * RCCL all-gather in vx_dist.py).  all_gather = 0: *out_grids receives ONE grid, on devices[0], holding the complete bitmask;
+ * all_gather = 1: out_grids[k] receives a complete grid on devices[k] for every k (rays can then be split over the devices).
+ * A device may appear more than once in `devices` (logical ranks: rehearsal on a box with fewer GPUs).  VX_GRID_BOOL and
+ * VX_GRID_AABBSTRUCT only: VX_GRID_VEC's list order needs triangle shards (vx_voxelize_opts.tri_begin/tri_end). */
+vx_status vx_voxelize_multi(const vx_mesh* mesh, float voxel_size, vx_grid_kind kind, int sat_variant, const int* devices, int num_devices, int all_gather,
+                            vx_grid** out_grids);
+
 /* ---- grid: replaces VoxelGrid<T> and its three subclasses ------------------------------------------------ */
 /* VoxelGrid ctor (voxelgrid.hpp:52-62): an empty grid of x*y*z voxels */
 vx_status vx_grid_create(vx_grid_kind kind, uint64_t x, uint64_t y, uint64_t z, float voxel_size, const float origin[3],

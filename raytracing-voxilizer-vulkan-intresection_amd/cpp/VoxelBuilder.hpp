@@ -17,6 +17,7 @@
 #include <filesystem>
 #include <string>
 #include <type_traits>
+#include <vector>
 
 #include "voxelgrid.hpp"
 #include "voxelgridAABBstruct.hpp"
@@ -69,9 +70,14 @@ public:
     // the reference today (every voxel MaterialObj{}, nothing recorded).
     VoxelBuilder& withMaterials(bool on = true) { m_materials = on; return *this; }
 
+    // Spreads buildVoxelGrid over several GPUs of this process (vx_voxelize_multi: word shards of the one grid, peer copies over
+    // xGMI; the grid returned lives on the first device).  Empty = the current device only.  VoxelGridBool / VoxelGridAABBstruct.
+    VoxelBuilder& withDevices(std::vector<int> devices) { m_devices = std::move(devices); return *this; }
+
 private:
     std::shared_ptr<vx_mesh> m_mesh;
     bool m_materials = false;
+    std::vector<int> m_devices;
 
     void readObjFile(const std::filesystem::path& path)
     {
@@ -91,7 +97,11 @@ public:
         opts.sat_variant = inParaell ? 1 : 0;
         opts.flags = m_materials ? VX_VOXELIZE_MATERIALS : 0;
         vx_grid* g = nullptr;
-        vxdetail::check(vx_voxelize(m_mesh.get(), voxelSize, vxdetail::kind_of<T>(), &opts, &g));
+        if (m_devices.size() > 1) {
+            if (m_materials) throw std::invalid_argument("withMaterials() and withDevices() cannot be combined");
+            vxdetail::check(vx_voxelize_multi(m_mesh.get(), voxelSize, vxdetail::kind_of<T>(), opts.sat_variant, m_devices.data(), (int)m_devices.size(), 0, &g));
+        } else
+            vxdetail::check(vx_voxelize(m_mesh.get(), voxelSize, vxdetail::kind_of<T>(), &opts, &g));
         vxdetail::GridHandle h = vxdetail::adopt(g);
         vx_grid_desc d;
         vxdetail::check(vx_grid_describe(g, &d));

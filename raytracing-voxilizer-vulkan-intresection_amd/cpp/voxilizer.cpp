@@ -14,6 +14,8 @@
 //                                       colour raytrace.rmiss:37, gamma post.frag:36.  Rays run on the GPU, the per-pixel shading
 //                                       arithmetic (display, not the hot path) on the host.  --camera-dump FILE writes the two 4x4
 //                                       matrices used (column-major float32), for comparisons.
+//   --gpus N [--logical]                spread the build over N GPUs of this node (word shards + peer copies, vx_voxelize_multi);
+//                                       --logical maps all N ranks onto device 0 (rehearsal on a box with fewer GPUs)
 //   --materials                         switch on the reference's commented-out material plumbing (usemtl / mtllib -> per-voxel
 //                                       material ids; VoxelBuilder.hpp:375-395): --render shades with them, --dump-materials FILE writes
 //                                       getMatIdx() as int16
@@ -145,10 +147,13 @@ int render(vx_grid* grid, const std::string& file, uint32_t W, uint32_t H, const
 
 template <class T, bool P>
 int run_grid(const std::string& path, float vs, const std::string& dumpFile, const char* label, const std::string& renderFile = "",
-             uint32_t rw = 1280, uint32_t rh = 720, bool materials = false, const std::string& matDump = "", const std::string& cameraDump = "")
+             uint32_t rw = 1280, uint32_t rh = 720, bool materials = false, const std::string& matDump = "", const std::string& cameraDump = "",
+             const std::vector<int>& devices = {})
 {
     VoxelBuilder<T, P> voxelBuilder{std::filesystem::path(path)};
     voxelBuilder.withMaterials(materials);
+    voxelBuilder.withDevices(devices);
+    if (devices.size() > 1) std::printf("[voxhip] build sharded over %zu ranks (first device %d)\n", devices.size(), devices[0]);
     const auto t0 = Clock::now();
     T vox = voxelBuilder.buildVoxelGrid(vs);
     const auto t1 = Clock::now();
@@ -183,7 +188,7 @@ int run_grid(const std::string& path, float vs, const std::string& dumpFile, con
 int main(int argc, char** argv)
 {
     if (argc < 3) {  // the reference reads argv[1], argv[2] unchecked (main.cpp:80,163)
-        std::fprintf(stderr, "usage: %s <Path to obj file> <Voxlesize> [--grid bool|aabbstruct|vec|octree] [--parallel] [--dump FILE] [--bench RUNS] [--render FILE.ppm [--size WxH] [--camera-dump FILE]] [--materials [--dump-materials FILE]]\n",
+        std::fprintf(stderr, "usage: %s <Path to obj file> <Voxlesize> [--grid bool|aabbstruct|vec|octree] [--parallel] [--dump FILE] [--bench RUNS] [--render FILE.ppm [--size WxH] [--camera-dump FILE]] [--materials [--dump-materials FILE]] [--gpus N [--logical]]\n",
                      argv[0]);
         return 2;
     }
@@ -192,7 +197,8 @@ int main(int argc, char** argv)
     try { vs = std::stof(argv[2]); } catch (const std::exception&) { std::fprintf(stderr, "invalid voxel size '%s'\n", argv[2]); return 2; }
     std::string grid = "bool", dumpFile, renderFile, matDump, cameraDump;
     uint32_t rw = 1280, rh = 720;  // main.cpp:72-73
-    bool parallel = false, materials = false;
+    bool parallel = false, materials = false, logical = false;
+    int gpus = 1;
     long benchRuns = 0;
     for (int i = 3; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--grid") && i + 1 < argc) grid = argv[++i];
@@ -201,10 +207,18 @@ int main(int argc, char** argv)
         else if (!std::strcmp(argv[i], "--bench") && i + 1 < argc) benchRuns = std::atol(argv[++i]);
         else if (!std::strcmp(argv[i], "--render") && i + 1 < argc) renderFile = argv[++i];
         else if (!std::strcmp(argv[i], "--materials")) materials = true;
+        else if (!std::strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = std::atoi(argv[++i]);
+        else if (!std::strcmp(argv[i], "--logical")) logical = true;
         else if (!std::strcmp(argv[i], "--dump-materials") && i + 1 < argc) matDump = argv[++i];
         else if (!std::strcmp(argv[i], "--camera-dump") && i + 1 < argc) cameraDump = argv[++i];
         else if (!std::strcmp(argv[i], "--size") && i + 1 < argc) { if (std::sscanf(argv[++i], "%ux%u", &rw, &rh) != 2) { std::fprintf(stderr, "bad --size\n"); return 2; } }
         else { std::fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
+    }
+    std::vector<int> devices;
+    if (gpus > 1) {
+        const int have = vx_device_count();
+        if (!logical && gpus > have) { std::fprintf(stderr, "--gpus %d but %d device(s) visible (add --logical to rehearse on one)\n", gpus, have); return 2; }
+        for (int k = 0; k < gpus; ++k) devices.push_back(logical ? 0 : k);
     }
     try {
         if (benchRuns > 0) {
@@ -226,8 +240,8 @@ int main(int argc, char** argv)
             dump(dumpFile, aabbs);
             return 0;
         }
-        if (grid == "bool") return parallel ? run_grid<VoxelGridBool, true>(path, vs, dumpFile, "VoxelGridBool", renderFile, rw, rh, materials, matDump, cameraDump)
-                                               : run_grid<VoxelGridBool, false>(path, vs, dumpFile, "VoxelGridBool", renderFile, rw, rh, materials, matDump, cameraDump);
+        if (grid == "bool") return parallel ? run_grid<VoxelGridBool, true>(path, vs, dumpFile, "VoxelGridBool", renderFile, rw, rh, materials, matDump, cameraDump, devices)
+                                               : run_grid<VoxelGridBool, false>(path, vs, dumpFile, "VoxelGridBool", renderFile, rw, rh, materials, matDump, cameraDump, devices);
         if (grid == "aabbstruct") return parallel ? run_grid<VoxelGridAABBstruct, true>(path, vs, dumpFile, "VoxelGridAABBstruct") : run_grid<VoxelGridAABBstruct, false>(path, vs, dumpFile, "VoxelGridAABBstruct");
         if (grid == "vec") return parallel ? run_grid<VoxelGridVec, true>(path, vs, dumpFile, "VoxelGridVec") : run_grid<VoxelGridVec, false>(path, vs, dumpFile, "VoxelGridVec");
         std::fprintf(stderr, "unknown grid flavour %s\n", grid.c_str());

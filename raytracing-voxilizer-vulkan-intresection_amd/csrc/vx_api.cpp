@@ -7,6 +7,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -870,6 +871,134 @@ vx_status vx_voxelize(const vx_mesh* mesh, float vs, vx_grid_kind kind, const vx
         return s;
     }
     *out = g;
+    return VX_OK;
+}
+
+// ---- multi-GPU build inside one process -----------------------------------------------------------------------------
+vx_status vx_voxelize_multi(const vx_mesh* mesh, float vs, vx_grid_kind kind, int sat_variant, const int* devices, int nd, int all_gather, vx_grid** out)
+{
+    if (!mesh || !devices || !out || nd < 1) return fail(VX_ERR_INVALID_ARG, "null argument");
+    if (kind != VX_GRID_BOOL && kind != VX_GRID_AABBSTRUCT)
+        return fail(VX_ERR_UNSUPPORTED, "vx_voxelize_multi builds VX_GRID_BOOL / VX_GRID_AABBSTRUCT (VX_GRID_VEC's list order needs triangle shards)");
+    if (mesh->borrowed) return fail(VX_ERR_UNSUPPORTED, "vx_voxelize_multi needs a mesh with host arrays (vx_mesh_load_obj / vx_mesh_from_arrays)");
+    VX_TRY(check_voxel_size(vs));
+    for (int k = 0; k < nd; ++k) VX_TRY(need_device(devices[k]));
+    const int prev_device = g_device;
+    // Rank 0 first: its unsharded bbox pass fixes the grid (dims, word count) every shard refers to.  Then one host thread per
+    // rank: a build waits twice for counts from its device, and the ranks should wait side by side.
+    std::vector<vx_mesh*> meshes((size_t)nd, nullptr);
+    std::vector<vx_grid*> grids((size_t)nd, nullptr);
+    std::vector<vx_status> st((size_t)nd, VX_OK);
+    std::vector<std::string> msg((size_t)nd);
+    auto cleanup = [&](bool keep_outputs) {
+        for (int k = 0; k < nd; ++k) {
+            if (meshes[(size_t)k]) vx_mesh_free(meshes[(size_t)k]);
+            if (grids[(size_t)k] && !(keep_outputs && (k == 0 || all_gather))) vx_grid_free(grids[(size_t)k]);
+        }
+        g_device = prev_device;
+    };
+    uint64_t nwords = 0;
+    {
+        // the grid's extent from a bbox-only pass on devices[0] (a zero-triangle shard of the same vertex set)
+        g_device = devices[0];
+        vx_status s0 = vx_mesh_from_arrays(mesh->hv.data(), mesh->nv, mesh->hi.data(), mesh->nt, &meshes[0]);
+        if (s0 != VX_OK) { cleanup(false); return s0; }
+        vx_grid* probe = nullptr;
+        vx_voxelize_opts po{};
+        po.sat_variant = sat_variant;
+        po.tri_begin = 0; po.tri_end = 0; po.word_begin = 0; po.word_end = 0;
+        // (tri_begin == tri_end == 0 means "all triangles"; the probe instead voxelizes the empty word range below)
+        po.word_begin = 1; po.word_end = 1;
+        s0 = vx_voxelize(meshes[0], vs, kind, &po, &probe);
+        if (s0 == VX_ERR_INVALID_ARG) {  // a grid without words (flat mesh): build it plainly
+            s0 = vx_voxelize(meshes[0], vs, kind, nullptr, &probe);
+            if (s0 != VX_OK) { cleanup(false); return s0; }
+            grids[0] = probe;
+            out[0] = probe;
+            if (all_gather)
+                for (int k = 1; k < nd; ++k) {
+                    g_device = devices[k];
+                    s0 = vx_mesh_from_arrays(mesh->hv.data(), mesh->nv, mesh->hi.data(), mesh->nt, &meshes[(size_t)k]);
+                    if (s0 == VX_OK) s0 = vx_voxelize(meshes[(size_t)k], vs, kind, nullptr, &grids[(size_t)k]);
+                    if (s0 != VX_OK) { cleanup(false); return s0; }
+                    out[k] = grids[(size_t)k];
+                }
+            cleanup(true);
+            return VX_OK;
+        }
+        if (s0 != VX_OK) { cleanup(false); return s0; }
+        nwords = probe->g.nwords;
+        vx_grid_free(probe);
+    }
+    auto worker = [&](int k) {
+        g_device = devices[k];  // thread-local
+        vx_status s = VX_OK;
+        if (!meshes[(size_t)k]) s = vx_mesh_from_arrays(mesh->hv.data(), mesh->nv, mesh->hi.data(), mesh->nt, &meshes[(size_t)k]);
+        if (s == VX_OK) {
+            vx_voxelize_opts o{};
+            o.sat_variant = sat_variant;
+            vx_shard_words(nwords, k, nd, &o.word_begin, &o.word_end, nullptr);
+            if (o.word_begin == o.word_end) { o.word_begin = o.word_end = (nwords ? 1 : 0); }  // an empty shard (more ranks than words)
+            s = vx_voxelize(meshes[(size_t)k], vs, kind, &o, &grids[(size_t)k]);
+        }
+        st[(size_t)k] = s;
+        if (s != VX_OK) msg[(size_t)k] = g_err;
+    };
+    {
+        std::vector<std::thread> th;
+        for (int k = 1; k < nd; ++k) th.emplace_back(worker, k);
+        worker(0);
+        for (auto& t : th) t.join();
+    }
+    for (int k = 0; k < nd; ++k)
+        if (st[(size_t)k] != VX_OK) { const vx_status s = st[(size_t)k]; const std::string m = msg[(size_t)k]; cleanup(false); return fail(s, m); }
+    // ---- exchange: every destination pulls the other ranks' word ranges as peer copies (one slab per source device)
+    const int ndst = all_gather ? nd : 1;
+    hipError_t e = hipSuccess;
+    for (int d = 0; d < ndst && e == hipSuccess; ++d) {
+        vx_grid* gd = grids[(size_t)d];
+        DeviceGuard dg(gd->device);
+        for (int k = 0; k < nd && e == hipSuccess; ++k) {
+            if (k == d) continue;
+            if (grids[(size_t)k]->device != gd->device) {  // direct xGMI copies instead of staging through the host
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, gd->device, grids[(size_t)k]->device) == hipSuccess && can) {
+                    const hipError_t pe = hipDeviceEnablePeerAccess(grids[(size_t)k]->device, 0);
+                    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+                    else if (pe == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+                }
+            }
+            uint64_t wb = 0, we = 0;
+            vx_shard_words(nwords, k, nd, &wb, &we, nullptr);
+            if (we <= wb) continue;
+            vx_grid* gk = grids[(size_t)k];
+            (void)hipStreamSynchronize(gk->stream);  // the source shard is complete (its build ran on another host thread / stream)
+            e = hipMemcpyPeerAsync(gd->words.as<uint32_t>() + wb, gd->device, gk->words.as<uint32_t>() + wb, gk->device, (size_t)(we - wb) * 4, gd->stream);
+        }
+    }
+    for (int d = 0; d < ndst && e == hipSuccess; ++d) {
+        DeviceGuard dg(grids[(size_t)d]->device);
+        e = hipStreamSynchronize(grids[(size_t)d]->stream);
+    }
+    if (e != hipSuccess) { cleanup(false); return fail(VX_ERR_HIP, std::string("peer exchange: ") + hipGetErrorString(e)); }
+    // ---- the complete masks: counts, word prefix and traversal structure; setVoxel calls of all shards add up
+    uint64_t calls = 0;
+    for (int k = 0; k < nd; ++k) {
+        vx_grid_desc dsc;
+        (void)sync_counts(grids[(size_t)k]);
+        calls += grids[(size_t)k]->set_calls;
+        (void)dsc;
+    }
+    for (int d = 0; d < ndst; ++d) {
+        vx_grid* gd = grids[(size_t)d];
+        gd->set_calls = calls;
+        gd->counts_valid = true;
+        gd->triangles = mesh->nt;
+        const vx_status s = vx_grid_refresh(gd);
+        if (s != VX_OK) { cleanup(false); return s; }
+        out[d] = gd;
+    }
+    cleanup(true);
     return VX_OK;
 }
 

@@ -56,7 +56,7 @@ SYMBOLS = [
     "vx_mesh_load_obj", "vx_mesh_from_arrays", "vx_mesh_from_device", "vx_mesh_num_vertices", "vx_mesh_num_triangles",
     "vx_mesh_host_vertices", "vx_mesh_host_indices", "vx_mesh_num_materials", "vx_mesh_materials", "vx_mesh_host_material_ids",
     "vx_mesh_set_materials", "vx_mesh_free",
-    "vx_voxelize", "vx_voxelize_into",
+    "vx_voxelize", "vx_voxelize_into", "vx_voxelize_multi",
     "vx_grid_create", "vx_grid_describe", "vx_grid_set_voxel", "vx_grid_test_voxel", "vx_grid_coords", "vx_grid_bytes",
     "vx_grid_bitmask", "vx_grid_bitmask_device", "vx_grid_bitmask_device_mut", "vx_grid_refresh", "vx_grid_aabbs",
     "vx_grid_aabbs_device", "vx_grid_materials", "vx_grid_material_ids", "vx_grid_material_ids_device", "vx_grid_free",
@@ -130,6 +130,7 @@ def lib():
     L.vx_mesh_free.restype = None
     L.vx_voxelize.argtypes = [vp, C.c_float, C.c_int, C.POINTER(VoxelizeOpts), C.POINTER(vp)]
     L.vx_voxelize_into.argtypes = [vp, C.c_float, C.POINTER(VoxelizeOpts), vp]
+    L.vx_voxelize_multi.argtypes = [vp, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(vp)]
     L.vx_grid_create.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_float, fp, vp, C.POINTER(vp)]
     L.vx_grid_describe.argtypes = [vp, C.POINTER(GridDesc)]
     L.vx_grid_set_voxel.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64]
@@ -321,6 +322,15 @@ class Grid:
         h = C.c_void_p()
         _check(lib().vx_voxelize(mesh.h, np.float32(voxel_size), kind, C.byref(o), C.byref(h)))
         return cls(h)
+
+    @classmethod
+    def voxelize_multi(cls, mesh, voxel_size, devices, kind=GRID_BOOL, sat_variant=0, all_gather=False):
+        """vx_voxelize_multi: word shards on the given devices + peer copies -> [grid on devices[0]] or one grid per device."""
+        dv = (C.c_int * len(devices))(*devices)
+        n = len(devices) if all_gather else 1
+        hs = (C.c_void_p * n)()
+        _check(lib().vx_voxelize_multi(mesh.h, np.float32(voxel_size), kind, sat_variant, dv, len(devices), 1 if all_gather else 0, hs))
+        return [cls(C.c_void_p(hs[i])) for i in range(n)]
 
     def revoxelize(self, mesh, voxel_size, sat_variant=0, words=None, tris=None, stream=None, materials=False):
         o = VoxelizeOpts()

@@ -71,6 +71,12 @@ def test_cli_contract(gpu, tmp_path):
     assert r.returncode == 0 and "Total usage of the Octree is 4144" in r.stdout, r.stdout
     r = run([exe, str(obj), "0.25", "--bench", "3"])
     assert r.returncode == 0 and "Voxel build took on avrage" in r.stdout and "AABB build took on avrage" in r.stdout
+    # the build spread over logical ranks (vx_voxelize_multi): the same list
+    r = run([exe, str(obj), "0.0625", "--dump", str(dump), "--gpus", "4", "--logical"])
+    assert r.returncode == 0 and "build sharded over 4 ranks" in r.stdout, r.stdout
+    assert open(dump, "rb").read() == oracle.bool_aabbs(ow, gi, np.float32(0.0625)).tobytes()
+    r = run([exe, str(obj), "0.0625", "--gpus", "64"])
+    assert r.returncode == 2 and "device(s) visible" in r.stdout
     # error paths
     r = run([exe, str(tmp_path / "nope.obj"), "0.1"])
     assert r.returncode == 1 and "Path does not exist!" in r.stdout

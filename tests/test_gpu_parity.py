@@ -581,7 +581,7 @@ def test_c4_atrium_1024_eight_shards(gpu):
         acc |= w
         total_calls += g.describe()["set_calls"]
     assert np.array_equal(acc, fw)
-    assert total_calls >= calls                         # hits of words split between two shards are counted by both owners' halves only once each
+    assert total_calls == calls                         # every setVoxel call lands in exactly one shard's words
 
 
 # ---------------------------------------------------------------------------------------------- per-voxel materials
@@ -662,3 +662,34 @@ def test_material_ids(gpu, name, vs, nmat, seed):
     assert (len(mats) == 1 and not mid.any() and len(mid) == g.describe()["occupied"]) or g.describe()["occupied"] == 0
     with pytest.raises(gpu.VxError):
         gpu.Grid.voxelize(mesh, vs, words=(0, 1), materials=True)
+
+
+# ---------------------------------------------------------------------------------------------- multi-GPU entry of the C ABI
+@pytest.mark.parametrize("nranks,all_gather", [(2, False), (3, True), (8, False)])
+@pytest.mark.parametrize("name,vs", [("adversarial", 0.03125), ("blob70k", 2.0 / 128)])
+def test_voxelize_multi_logical_ranks(gpu, name, vs, nranks, all_gather):
+    """vx_voxelize_multi with logical ranks on the one device of the test box: word shards + peer copies give the single-GPU
+    grid -- bitmask, counts, AABB list, and a grid that traces (prefix + traversal structure rebuilt from the gathered mask)."""
+    v, t = vx_scenes.scene(name)
+    vs = np.float32(vs)
+    mesh = gpu.Mesh.from_arrays(v, t)
+    ow, calls, gi = oracle.build_bool(v, t, vs)     # serial driver = SAT a7, as sat_variant 0 (the threaded driver's a8 has no epsilon skips)
+    oa = oracle.bool_aabbs(ow, gi, vs)
+    grids = gpu.Grid.voxelize_multi(mesh, vs, [0] * nranks, all_gather=all_gather)
+    assert len(grids) == (nranks if all_gather else 1)
+    rays = vx_scenes.random_rays(3000, gi["bmin"], gi["bmax"], seed=91)
+    for g in grids:
+        d = g.describe()
+        assert d["dim"] == gi["dim"] and d["occupied"] == len(oa) and d["set_calls"] == calls and d["triangles"] == len(t)
+        assert np.array_equal(g.bitmask(), ow)
+        assert g.aabbs().tobytes() == oa.tobytes()
+        check_trace(gpu, g, oa, rays)
+    with pytest.raises(gpu.VxError):
+        gpu.Grid.voxelize_multi(mesh, vs, [0, 0], kind=gpu.GRID_VEC)
+    # more ranks than words, and a flat mesh (no words at all)
+    v2, t2 = vx_scenes.cube()
+    g2 = gpu.Grid.voxelize_multi(gpu.Mesh.from_arrays(v2, t2), np.float32(0.5), [0] * 5)[0]
+    w2, _, _ = oracle.build_bool(v2, t2, np.float32(0.5))
+    assert np.array_equal(g2.bitmask(), w2)
+    flat = gpu.Grid.voxelize_multi(gpu.Mesh.from_arrays(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32), np.array([[0, 1, 2]], np.int32)), 0.1, [0, 0])[0]
+    assert flat.describe()["occupied"] == 0 and flat.describe()["dim"][2] == 0
