@@ -2,8 +2,9 @@
 """bench.py -- one "step" = one pass of the hot path over one batch of synthetic input, inputs resident in HBM:
 
     VoxelGridVec-flavoured buildVoxelGrid (bbox, grid dims, SAT voxelization into the occupancy bitmask AND the
-    ordered-with-duplicates AABB list)  ->  getAabbs (for the Vec flavour the list the build produced: a device copy;
-    `--flavour bool` runs VoxelGridBool::getAabbs = scan + k_emit_bool instead)  ->  first-hit trace of R rays.
+    ordered-with-duplicates AABB list)  ->  getAabbs (for the Vec flavour the list the build produced, emitted straight into the
+    consumer's device buffer (vx_grid_bind_aabbs_device); `--flavour bool` runs VoxelGridBool::getAabbs = scan + k_emit_bool
+    instead)  ->  first-hit trace of R rays.
 
 Workload (N=1): BASELINE.json configs[2] -- the Sponza-like `atrium262k` scene (261 496 triangles, synthetic: the reference
 ships no meshes) at voxelsize 32/512 = exactly 512^3 cells, VecEncoding path, with configs[1]'s ray recipe (1M random rays,
@@ -183,6 +184,8 @@ def main():
     # the Bool flavour one per occupied voxel -- for N > 1 the unsharded count, the timed loop rebuilds the mask from shards)
     cap = max(desc["set_calls"] if kind == voxhip.GRID_VEC else desc["occupied"], 1)
     d_aabbs = torch.empty(cap * 6, dtype=torch.float32, device=dev)
+    if kind == voxhip.GRID_VEC:
+        grid.bind_aabbs_device(d_aabbs.data_ptr(), cap)   # the list is built in the consumer's buffer: getAabbs has nothing left to copy
     exch = vx_dist.Exchange(nwords, rank, world, dev, dist) if world > 1 else None
 
     # stage boundaries: five events per timed step, all read AFTER the timed region (reading them per step needs a device

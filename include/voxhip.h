@@ -166,6 +166,12 @@ vx_status vx_grid_refresh(vx_grid* g);            /* recount + rebuild derived d
  * *count receives the list length; at most `capacity` entries are written (capacity 0 = size query). */
 vx_status vx_grid_aabbs(const vx_grid* g, vx_aabb* host_out, uint64_t capacity, uint64_t* count);
 vx_status vx_grid_aabbs_device(const vx_grid* g, vx_aabb* dev_out, uint64_t capacity, uint64_t* count);
+/* VX_GRID_VEC: hand the grid the device buffer its list should be built IN (VoxelGridVec::getAabbs returns a copy of m_voxel,
+ * voxelgridVecEncoding.cpp:15-18; a caller that wants the list in its own HBM buffer saves that copy).  Later vx_voxelize_into
+ * calls emit straight into dev_out when the list fits `capacity` entries (otherwise into the grid's own storage, as without a
+ * binding), and vx_grid_aabbs_device(g, dev_out, ...) then has nothing left to copy.  The buffer must outlive the binding;
+ * dev_out NULL / capacity 0 removes it.  No effect on the other flavours (their lists are emitted by vx_grid_aabbs_device). */
+vx_status vx_grid_bind_aabbs_device(vx_grid* g, vx_aabb* dev_out, uint64_t capacity);
 /* getMatrials() / getMatIdx() (voxelgrid.hpp:74-89) of a grid built with VX_VOXELIZE_MATERIALS:
  *   materials     the distinct MaterialObj values in the order addMatrialIfNeeded first met them (equality = MaterialObj::operator==,
  *                 obj_loader.h:45-51: every field except ior and dissolve; a face without usemtl carries MaterialObj{});

@@ -48,13 +48,14 @@ def build_lib(force=False, verbose=False):
     # a change of flags (diagnostic -D builds) invalidates every object
     stamp = os.path.join(objdir, "flags.txt")
     flags_now = " ".join(FLAGS)
-    if not os.path.exists(stamp) or open(stamp).read() != flags_now:
-        force = True
+    flags_changed = not os.path.exists(stamp) or open(stamp).read() != flags_now
+    # VOXHIP_VARIANT_ONLY=a.hip,b.hip: the extra -D flags only concern these sources (parameter sweeps of one kernel)
+    only = [x for x in os.environ.get("VOXHIP_VARIANT_ONLY", "").split(",") if x]
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
         obj = os.path.join(objdir, src + ".o")
         objs.append(obj)
-        if force or _newer(obj, [sp] + hdrs):
+        if force or (flags_changed and (not only or src in only)) or _newer(obj, [sp] + hdrs):
             cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", sp, "-o", obj]
             if verbose:
                 print(" ".join(cmd))

@@ -281,6 +281,11 @@ struct vx_grid {
     bool coarse_valid = false, prefix_valid = false /*word_prefix queued or done*/, occupied_known = false, counts_valid = true;
     uint64_t occupied = 0, set_calls = 0, host_set_calls = 0;
     uint64_t vec_count = 0;
+    // VX_GRID_VEC: the caller's own list buffer (vx_grid_bind_aabbs_device); builds emit straight into it when it is large enough
+    vx_aabb* bound = nullptr;
+    uint64_t bound_cap = 0;
+    bool vec_in_bound = false;  // the current list lives in `bound`, not in `vec`
+    vx_aabb* vec_ptr() const { return vec_in_bound ? bound : reinterpret_cast<vx_aabb*>(vec.p); }
     Mail* mail = nullptr;
     void set_dev(int d)
     {
@@ -795,10 +800,13 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
     if (g->kind == VX_GRID_VEC) {
         // The list is emitted into the handle's existing buffer before the host knows the hit count (writes beyond the
         // buffer's capacity are dropped by the kernel); only a list that outgrew it is emitted again after the wait.
-        const uint64_t cap_rec = g->vec.p ? g->vec.cap / sizeof(vx_aabb) : 0;
+        const bool to_bound = g->bound != nullptr && g->bound_cap > 0;
+        vx_aabb* tgt = to_bound ? g->bound : g->vec.as<vx_aabb>();
+        const uint64_t cap_rec = to_bound ? g->bound_cap + 1 : (g->vec.p ? g->vec.cap / sizeof(vx_aabb) : 0);
+        g->vec_in_bound = false;
         if (cap_rec)
             vx::launch_emit_units(g->recs.as<vx::TriRec>(), g->ubase.as<uint32_t>(), g->btri.as<uint32_t>(), ntri, g->g, umask,
-                                  g->hbase.as<uint32_t>(), g->vec.as<vx_aabb>(), nullptr, s, cap_rec);
+                                  g->hbase.as<uint32_t>(), tgt, nullptr, s, to_bound ? g->bound_cap : cap_rec);
         VX_HIP(hipStreamSynchronize(s));
         const unsigned long long hits = g->mail->hits;
         if (hits >= 0xFFFFFFFFull) return fail(VX_ERR_CAPACITY, "more than 2^32 voxel hits");
@@ -807,6 +815,7 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
             g->occupied = g->mail->occupied;
             g->occupied_known = true;
         }
+        if (hits + 1 <= cap_rec) g->vec_in_bound = to_bound;
         if (hits + 1 > cap_rec) {
             VX_HIP(g->vec.ensure((size_t)(hits + 1) * sizeof(vx_aabb)));
             vx::launch_emit_units(g->recs.as<vx::TriRec>(), g->ubase.as<uint32_t>(), g->btri.as<uint32_t>(), ntri, g->g, umask,
@@ -1059,6 +1068,11 @@ vx_status vx_grid_set_voxel(vx_grid* g, uint64_t x, uint64_t y, uint64_t z)
         vx_aabb b;
         vx::cell_aabb(g->g, (uint32_t)x, (uint32_t)y, (uint32_t)z, b.minimum);
         const size_t need = (size_t)(g->vec_count + 1) * sizeof(vx_aabb);
+        if (g->vec_in_bound) {  // the list lives in the caller's buffer: appending continues in the grid's own storage
+            VX_HIP(g->vec.ensure(need * 2));
+            if (g->vec_count) VX_HIP(hipMemcpyAsync(g->vec.p, g->bound, (size_t)g->vec_count * sizeof(vx_aabb), hipMemcpyDeviceToDevice, g->stream));
+            g->vec_in_bound = false;
+        }
         if (need > g->vec.cap) {
             DevBuf nb;
             nb.dev = g->device;
@@ -1148,7 +1162,8 @@ vx_status vx_grid_aabbs_device(const vx_grid* gc, vx_aabb* dev_out, uint64_t cap
     if (g->kind == VX_GRID_VEC) {
         if (count) *count = g->vec_count;
         const uint64_t n = cap < g->vec_count ? cap : g->vec_count;
-        if (n && dev_out) VX_HIP(hipMemcpyAsync(dev_out, g->vec.p, (size_t)n * sizeof(vx_aabb), hipMemcpyDeviceToDevice, g->stream));
+        if (n && dev_out && dev_out != g->vec_ptr())  // (a bound buffer already holds the list: nothing to copy)
+            VX_HIP(hipMemcpyAsync(dev_out, g->vec_ptr(), (size_t)n * sizeof(vx_aabb), hipMemcpyDeviceToDevice, g->stream));
         return VX_OK;
     }
     // queue the prefix scan and the emission back to back, then wait once for the count
@@ -1174,7 +1189,7 @@ vx_status vx_grid_aabbs(const vx_grid* gc, vx_aabb* host_out, uint64_t cap, uint
     const uint64_t m = cap < n ? cap : n;
     if (!m || !host_out) return VX_OK;
     if (g->kind == VX_GRID_VEC) {
-        VX_HIP(hipMemcpyAsync(host_out, g->vec.p, (size_t)m * sizeof(vx_aabb), hipMemcpyDeviceToHost, g->stream));
+        VX_HIP(hipMemcpyAsync(host_out, g->vec_ptr(), (size_t)m * sizeof(vx_aabb), hipMemcpyDeviceToHost, g->stream));
         VX_HIP(hipStreamSynchronize(g->stream));
         return VX_OK;
     }
@@ -1187,6 +1202,21 @@ vx_status vx_grid_aabbs(const vx_grid* gc, vx_aabb* host_out, uint64_t cap, uint
     if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
     tmp.release();
     VX_HIP(e);
+    return VX_OK;
+}
+
+vx_status vx_grid_bind_aabbs_device(vx_grid* g, vx_aabb* dev_out, uint64_t capacity)
+{
+    if (!g) return fail(VX_ERR_INVALID_ARG, "null argument");
+    if (g->vec_in_bound && g->vec_count) {  // keep the current list reachable: move it into the grid's own storage first
+        DeviceGuard dg(g->device);
+        VX_HIP(g->vec.ensure((size_t)(g->vec_count + 1) * sizeof(vx_aabb)));
+        VX_HIP(hipMemcpyAsync(g->vec.p, g->bound, (size_t)g->vec_count * sizeof(vx_aabb), hipMemcpyDeviceToDevice, g->stream));
+        VX_HIP(hipStreamSynchronize(g->stream));
+    }
+    g->vec_in_bound = false;
+    g->bound = capacity ? dev_out : nullptr;
+    g->bound_cap = dev_out ? capacity : 0;
     return VX_OK;
 }
 

@@ -379,14 +379,20 @@ __device__ unsigned long long g_walk_dbg[24];
 #ifndef VOXHIP_DONATE_ON
 #define VOXHIP_DONATE_ON (P.donate != 0)
 #endif
+#ifndef VX_W_DON_BELOW
+#define VX_W_DON_BELOW 48
+#endif
+#ifndef VX_W_DON_BRICKS
+#define VX_W_DON_BRICKS 6.0f
+#endif
 #ifndef VX_W_STEPS
-#define VX_W_STEPS 4
+#define VX_W_STEPS 2
 #endif
 #ifndef VX_W_ITERS
-#define VX_W_ITERS 2
+#define VX_W_ITERS 1
 #endif
 #ifndef VX_W_REFILL
-#define VX_W_REFILL 48
+#define VX_W_REFILL 56
 #endif
 #ifndef VX_W_CHUNK
 #define VX_W_CHUNK 64
@@ -646,8 +652,8 @@ __global__ __launch_bounds__(VX_W_BLOCK, VX_W_MINWAVES) void k_walk(const WalkPa
     // (t bits << 32 | voxel index), the same "closest, then lower index" order a single walk uses, and a piece count; the piece
     // that finishes last writes the ray's outputs.  Slot = the lane that held the ray when it was first split.
     constexpr bool kDonate = sizeof(IdxT) == 4;       // the merge key holds the voxel index in 32 bits
-    constexpr int kDonateBelow = 48;                  // donate while at most this many lanes are busy
-    constexpr float kDonateBricks = 6.0f;             // ... and only from pieces with more than this many brick slabs left
+    constexpr int kDonateBelow = VX_W_DON_BELOW;       // donate while at most this many lanes are busy
+    constexpr float kDonateBricks = VX_W_DON_BRICKS;  // ... and only from pieces with more than this many brick slabs left
     __shared__ unsigned long long don_key[VX_W_BLOCK];
     __shared__ unsigned don_cnt[VX_W_BLOCK];
     const int lane = threadIdx.x & 63;

@@ -59,7 +59,7 @@ SYMBOLS = [
     "vx_voxelize", "vx_voxelize_into", "vx_voxelize_multi",
     "vx_grid_create", "vx_grid_describe", "vx_grid_set_voxel", "vx_grid_test_voxel", "vx_grid_coords", "vx_grid_bytes",
     "vx_grid_bitmask", "vx_grid_bitmask_device", "vx_grid_bitmask_device_mut", "vx_grid_refresh", "vx_grid_aabbs",
-    "vx_grid_aabbs_device", "vx_grid_materials", "vx_grid_material_ids", "vx_grid_material_ids_device", "vx_grid_free",
+    "vx_grid_aabbs_device", "vx_grid_bind_aabbs_device", "vx_grid_materials", "vx_grid_material_ids", "vx_grid_material_ids_device", "vx_grid_free",
     "vx_octree_build", "vx_octree_num_items", "vx_octree_num_nodes", "vx_octree_bytes", "vx_octree_items", "vx_octree_nodes",
     "vx_octree_root_bounds", "vx_octree_aabbs", "vx_octree_aabbs_device", "vx_octree_free",
     "vx_trace", "vx_trace_device", "vx_trace_primary_device", "vx_trace_ex", "vx_trace_ex_device",
@@ -146,6 +146,7 @@ def lib():
     L.vx_grid_refresh.argtypes = [vp]
     L.vx_grid_aabbs.argtypes = [vp, vp, C.c_uint64, u64p]
     L.vx_grid_aabbs_device.argtypes = [vp, vp, C.c_uint64, u64p]
+    L.vx_grid_bind_aabbs_device.argtypes = [vp, vp, C.c_uint64]
     L.vx_grid_materials.argtypes = [vp, vp, C.c_uint64, u64p]
     L.vx_grid_material_ids.argtypes = [vp, vp, C.c_uint64, u64p]
     L.vx_grid_material_ids_device.argtypes = [vp]
@@ -406,6 +407,10 @@ class Grid:
         if n.value:
             _check(lib().vx_grid_material_ids(self.h, ids.ctypes.data, n.value, C.byref(n)))
         return recs, ids
+
+    def bind_aabbs_device(self, dev_ptr, capacity):
+        """VX_GRID_VEC: later revoxelize() calls build the list straight in this device buffer (None / 0 removes the binding)."""
+        _check(lib().vx_grid_bind_aabbs_device(self.h, dev_ptr, capacity))
 
     def aabbs_device(self, dev_ptr, capacity):
         n = C.c_uint64()

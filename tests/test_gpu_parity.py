@@ -693,3 +693,33 @@ def test_voxelize_multi_logical_ranks(gpu, name, vs, nranks, all_gather):
     assert np.array_equal(g2.bitmask(), w2)
     flat = gpu.Grid.voxelize_multi(gpu.Mesh.from_arrays(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32), np.array([[0, 1, 2]], np.int32)), 0.1, [0, 0])[0]
     assert flat.describe()["occupied"] == 0 and flat.describe()["dim"][2] == 0
+
+
+def test_vec_list_bound_to_caller_buffer(gpu):
+    """vx_grid_bind_aabbs_device: VoxelGridVec builds emit straight into the caller's device buffer (no copy in getAabbs); a buffer
+    that is too small falls back to the grid's own storage; setVoxel appends and re-binding keep the list intact."""
+    import torch
+    v, t = vx_scenes.scene("soup2000")
+    vs = np.float32(0.02)
+    mesh = gpu.Mesh.from_arrays(v, t)
+    ov = oracle.build_vec(v, t, vs)
+    g = gpu.Grid.voxelize(mesh, vs, gpu.GRID_VEC)
+    buf = torch.zeros((len(ov) + 8) * 6, dtype=torch.float32, device="cuda")
+    g.bind_aabbs_device(buf.data_ptr(), len(ov) + 8)
+    g.revoxelize(mesh, vs)
+    torch.cuda.synchronize()
+    assert buf.cpu().numpy()[: len(ov) * 6].tobytes() == ov.tobytes()            # the build itself filled the caller's buffer
+    assert g.aabbs_device(buf.data_ptr(), len(ov) + 8) == len(ov)
+    assert g.aabbs().tobytes() == ov.tobytes()
+    # appending by setVoxel migrates the list into the grid's own storage
+    g.set_voxel(0, 0, 0)
+    a = g.aabbs()
+    assert len(a) == len(ov) + 1 and a[: len(ov)].tobytes() == ov.tobytes()
+    # a binding that is too small: the build falls back, the list is still right
+    small = torch.zeros(60, dtype=torch.float32, device="cuda")
+    g.bind_aabbs_device(small.data_ptr(), 10)
+    g.revoxelize(mesh, vs)
+    assert g.aabbs().tobytes() == ov.tobytes()
+    g.bind_aabbs_device(None, 0)
+    g.revoxelize(mesh, np.float32(0.031))
+    assert g.aabbs().tobytes() == oracle.build_vec(v, t, np.float32(0.031)).tobytes()
