@@ -192,6 +192,7 @@ struct WalkLane {
     float best;              // best accepted t so far (+inf: none)
     IdxT best_idx;           // voxel index of the best hit (all ones: none)
     int lvl, k;              // current slab: level (2 block slabs, 1 brick slabs; 0: inside a brick of brick slab k) and its index along w
+    int cw0;                 // cell index along w where this ray (or piece) starts, one cell of slack: slabs wholly in front of it are never looked at
     // occupied bricks of the current brick slab's rectangle, waiting for the brick phase
     uint32_t pend;           // bits 0..15: brick jb + j = (cu0 + (jb + j) % nu, cv0 + (jb + j) / nu) is occupied; bits 16..30: nu; bit 31: more windows
     int jb;                  // first rectangle cell of the current 16-cell window (0 unless the rectangle has more than 16 cells)
@@ -312,6 +313,7 @@ __device__ __forceinline__ bool walk_setup(WalkLane<IdxT>& R, const GridParams& 
     int cw = (int)floorf((pw - R.orgw) * inv_vs) + (pos ? -1 : 1);
     cw = cw < 0 ? 0 : (cw > R.dimw - 1 ? R.dimw - 1 : cw);
     R.k = cw >> 6;
+    R.cw0 = cw;
     return true;
 }
 
@@ -447,9 +449,14 @@ __device__ __forceinline__ void walk_fetch_brick(WalkLane<IdxT>& R, const WalkHo
     const unsigned long long col = (unsigned long long)((2u << a1) - (1u << a0)) * 0x0101010101010101ull;
     const unsigned long long rect = col & (~0ull >> (8 * (7 - b1))) & (~0ull << (8 * b0));
     R.w0 = w01.x; R.w1 = w01.y; R.w2 = w23.x; R.w3 = w23.y; R.w4 = w45.x; R.w5 = w45.y; R.w6 = w67.x; R.w7 = w67.y;
-    R.sm = ((w01.x & rect) ? 1u : 0u) | ((w01.y & rect) ? 2u : 0u) | ((w23.x & rect) ? 4u : 0u) | ((w23.y & rect) ? 8u : 0u) |
-           ((w45.x & rect) ? 16u : 0u) | ((w45.y & rect) ? 32u : 0u) | ((w67.x & rect) ? 64u : 0u) | ((w67.y & rect) ? 128u : 0u);
-    R.pc = (R.pc & 0u) | (uint32_t)cu | ((uint32_t)cv << 16);  // from here on: the brick itself (its rectangle cell is popped from R.pend below)
+    uint32_t sm = ((w01.x & rect) ? 1u : 0u) | ((w01.y & rect) ? 2u : 0u) | ((w23.x & rect) ? 4u : 0u) | ((w23.y & rect) ? 8u : 0u) |
+                  ((w45.x & rect) ? 16u : 0u) | ((w45.y & rect) ? 32u : 0u) | ((w67.x & rect) ? 64u : 0u) | ((w67.y & rect) ? 128u : 0u);
+    // slabs wholly in front of the ray's start cell are never looked at
+    const int s0 = R.cw0 - (R.k << 3);  // slab of this brick that holds the start cell (negative: in front of the brick)
+    if (R.iw > 0.0f) sm &= s0 <= 0 ? 0xFFu : (s0 > 7 ? 0u : (0xFFu << s0));
+    else sm &= s0 >= 7 ? 0xFFu : (s0 < 0 ? 0u : (2u << s0) - 1u);
+    R.sm = sm & 0xFFu;
+    R.pc = (uint32_t)cu | ((uint32_t)cv << 16);  // from here on: the brick itself (its rectangle cell is popped from R.pend below)
 }
 
 // One step of the walk = one slab: a block slab (level 2), a brick slab (level 1), or one 1-cell slab of the brick being walked
@@ -565,7 +572,10 @@ __device__ __forceinline__ bool walk_step(WalkLane<IdxT>& R, const WalkHot& P, c
             if (occ) {
                 if (top) {  // down into the eight brick slabs of this block slab
                     const int ncw = (R.dimw + 7) >> 3;
-                    int kf = pos ? (k << 3) : (k << 3) + 7;
+                    // the first brick slab of this block slab -- not in front of the ray's start cell
+                    const int ks = R.cw0 >> 3;
+                    int kf = pos ? ((k << 3) > ks ? (k << 3) : ks) : ((k << 3) + 7 < ks ? (k << 3) + 7 : ks);
+                    kf = kf < (k << 3) ? (k << 3) : (kf > (k << 3) + 7 ? (k << 3) + 7 : kf);
                     kf = kf > ncw - 1 ? ncw - 1 : kf;
                     R.lvl = 1;
                     R.k = kf;
@@ -589,24 +599,30 @@ __device__ __forceinline__ bool walk_step(WalkLane<IdxT>& R, const WalkHot& P, c
     if (R.lvl == 0) {
         // ---- level 0 bookkeeping: next brick of the brick slab's rectangle once this one is done; back to level 1 after the last
         if (!brick_done) return true;
-        if (lvl == 0) {  // the brick just finished: pop it; R.pc goes back to the rectangle's first brick for the decode of the next one
-            const uint32_t low = R.pend & 0xFFFFu;
-            const uint32_t rest = low & (low - 1u);
-            // recover (cu0, cv0): the finished brick was rectangle cell j = jb + ffs(low) - 1
-            const int nu = (int)((R.pend >> 16) & 0x7FFFu);
-            int jv = 0, ju = R.jb + __ffs(low) - 1;
-            while (ju >= nu) { ju -= nu; ++jv; }
-            R.pc = (uint32_t)((int)(R.pc & 0xFFFFu) - ju) | ((uint32_t)((int)(R.pc >> 16) - jv) << 16);
-            R.pend = (R.pend & 0xFFFF0000u) | rest;
-        }
-        if (R.pend & 0xFFFFu) {
-            walk_fetch_brick(R, P VX_W_SITE_ARGS);  // (a brick with nothing inside the rectangle is popped by the next step)
-            return true;
+        // `dead`: this step found that no box of its slab or of any later slab can beat the best hit; only the sibling bricks of the
+        // same brick slab lie beside and not behind.  Without one the ray is finished -- no step is spent on rediscovering that at
+        // the next brick slab and the next block slab.
+        const bool dead = stop && !brick_empty;
+        bool pop = lvl == 0;  // a brick was being walked
+        for (;;) {
+            if (pop) {  // R.pc goes back to the rectangle's first brick for the decode of the next one
+                const uint32_t low = R.pend & 0xFFFFu;
+                const int nu = (int)((R.pend >> 16) & 0x7FFFu);
+                int jv = 0, ju = R.jb + __ffs(low) - 1;  // the finished brick was rectangle cell j = jb + ffs(low) - 1
+                while (ju >= nu) { ju -= nu; ++jv; }
+                R.pc = (uint32_t)((int)(R.pc & 0xFFFFu) - ju) | ((uint32_t)((int)(R.pc >> 16) - jv) << 16);
+                R.pend = (R.pend & 0xFFFF0000u) | (low & (low - 1u));
+            }
+            if (!(R.pend & 0xFFFFu)) break;
+            walk_fetch_brick(R, P VX_W_SITE_ARGS);
+            if (R.sm != 0u) return true;
+            pop = true;  // nothing of this brick inside the rectangle: on to the next without spending a step
         }
         const bool more = (R.pend >> 31) != 0u;
         R.pend = 0u;
         R.lvl = 1;
         if (more) { R.jb += 16; return true; }  // the same brick slab's next window of rectangle cells
+        if (dead) return false;
     }
     R.jb = 0;
     return walk_advance(R);
@@ -798,6 +814,7 @@ __global__ __launch_bounds__(VX_W_BLOCK, VX_W_MINWAVES) void k_walk(const WalkPa
                         int cw = (int)floorf((pw - s_orgw) * P.inv_vs) + (s_iw > 0.0f ? -1 : 1);
                         cw = cw < 0 ? 0 : (cw > s_dimw - 1 ? s_dimw - 1 : cw);
                         R.k = cw >> 6;
+                        R.cw0 = cw;
                         r = s_r;
                         slot = s_slot;
                         busy = true;

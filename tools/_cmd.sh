@@ -1,2 +1,3 @@
-export TB_NOCHECK=1 TB_SIZES=1,2,8
-bash tools/variant_trace.sh "-DVX_W_STEPS=1 -DVX_W_ITERS=1" "-DVX_W_STEPS=2 -DVX_W_ITERS=1" "-DVX_W_STEPS=3 -DVX_W_ITERS=1" "-DVX_W_STEPS=2 -DVX_W_ITERS=1 -DVX_W_REFILL=56" "-DVX_W_STEPS=2 -DVX_W_ITERS=1 -DVX_W_REFILL=40" "-DVX_W_STEPS=2 -DVX_W_ITERS=1 -DVX_W_REFILL=63"
+mkdir -p gpurun_out/r2p
+python tools/trace_bench.py > gpurun_out/r2p/tb_walk.log 2>&1; tail -1 gpurun_out/r2p/tb_walk.log
+timeout -k 10 900 python -m pytest tests/test_gpu_configs.py tests/test_gpu_parity.py -m gpu -q -x --timeout 900 -k "trace or ray or shadow or tiny or far or random or reuse or primary or c3 or c4 or c5 or multi" > gpurun_out/r2p/pytest.log 2>&1; tail -5 gpurun_out/r2p/pytest.log
