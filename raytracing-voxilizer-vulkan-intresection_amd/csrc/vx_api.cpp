@@ -440,7 +440,7 @@ vx_status setup_finish(uint32_t ntri, DevBuf& ubase, DevBuf& btri, Mail* mail, h
     if (tot >= 0xFFFFFFFFull) return fail(VX_ERR_CAPACITY, "more than 2^32 candidate row segments: shard the mesh or the grid");
     *total_units = tot;
     if (tot) {
-        VX_HIP(btri.ensure((size_t)(tot / 256 + 2) * 4));
+        VX_HIP(btri.ensure((size_t)(tot / 64 + 2) * 4));
         vx::launch_unit_blocks(ubase.as<uint32_t>(), ntri, (uint32_t)tot, btri.as<uint32_t>(), s);
     }
     return VX_OK;

@@ -564,23 +564,25 @@ __device__ __forceinline__ TriRec load_rec(const TriRec* __restrict__ recs, uint
 
 // ------------------------------------------------------------------------------------------------------------
 // Unit -> triangle lookup without a per-lane global binary search (K2 was latency-bound on it: 61 % of wave cycles in
-// s_waitcnt).  k_unit_blocks records, for every 256-unit block, the triangle that owns the block's first unit; a workgroup
-// then stages the unit bases and the 48-byte records of the (few) triangles its 256 units belong to in LDS and every lane
-// searches there.  Blocks that span too many triangles (long runs of zero-unit triangles) fall back to the global search.
+// s_waitcnt).  k_unit_blocks records, for every 64-unit block, the triangle that owns the block's first unit; a WAVE then
+// stages the unit bases and the 48-byte records of the (few) triangles its 64 units belong to in its own piece of LDS and
+// every lane searches there.  Blocks that span too many triangles (long runs of zero-unit triangles) fall back to the
+// global search.  Nothing in the scheme synchronises waves with each other.
 // ------------------------------------------------------------------------------------------------------------
-constexpr uint32_t kStageTris = 192;
+constexpr uint32_t kStageTris = 64;
+constexpr uint32_t kUnitBlockLog2 = 6;
 
-// One thread per 256-unit block: binary search of the unit bases for the triangle that owns the block's first unit (the
-// largest t with unit_base[t] <= 256 b; triangles without units share their base with the next one and are skipped by taking
+// One thread per 64-unit block: binary search of the unit bases for the triangle that owns the block's first unit (the
+// largest t with unit_base[t] <= 64 b; triangles without units share their base with the next one and are skipped by taking
 // the LAST such t).  The previous form -- one thread per triangle writing the blocks it spans -- serialised on the few
 // triangles that span hundreds of blocks.
 __global__ __launch_bounds__(256) void k_unit_blocks(const uint32_t* __restrict__ unit_base, uint32_t ntri, uint32_t* __restrict__ block_tri)
 {
     const uint32_t U = unit_base[ntri];
-    const uint32_t nUB = (U + 255u) >> 8;
+    const uint32_t nUB = (U + 63u) >> kUnitBlockLog2;
     const uint32_t b = blockIdx.x * 256u + threadIdx.x;
     if (b >= nUB) return;
-    const uint32_t u = b << 8;
+    const uint32_t u = b << kUnitBlockLog2;
     uint32_t lo = 0, hi = ntri;  // unit_base[lo] <= u < unit_base[hi]
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
@@ -591,38 +593,91 @@ __global__ __launch_bounds__(256) void k_unit_blocks(const uint32_t* __restrict_
 
 void launch_unit_blocks(const uint32_t* unit_base, uint32_t ntri, uint32_t total_units, uint32_t* block_tri, hipStream_t s)
 {
-    const uint32_t nUB = (total_units + 255u) >> 8;
+    const uint32_t nUB = (total_units + 63u) >> kUnitBlockLog2;
     if (!ntri || !nUB) return;
     VX_KL(k_unit_blocks, dim3((nUB + 255) / 256), dim3(256), 0, s, unit_base, ntri, block_tri);
 }
 
-struct UnitStage {
-    uint32_t base[kStageTris + 4];
-    float4 rec[kStageTris * 3];
-};
+#ifdef VX_VOX_DEBUG
+// diagnostic build: wave cycles per phase of for_each_unit: [4] wait for outstanding memory operations at the top of a pass,
+// [0] issue of the next pass's staging, [1] unit search + record read, [2] the functor (SAT / emission), [3] rest
+__device__ unsigned long long g_vox_dbg[8];
+#define VX_V_T(i) { const unsigned long long now_ = __builtin_readcyclecounter(); vdbg[i] += now_ - vlast; vlast = now_; }
+#else
+#define VX_V_T(i)
+#endif
 
-// Calls f(u, triangle, record, u - unit_base[triangle]) for every work unit, one unit per lane, 256 per workgroup pass.
+struct __attribute__((aligned(16))) UnitStage {  // one wave's staging buffer
+    float4 rec[kStageTris * 3];
+    uint32_t base[kStageTris];
+};
+constexpr uint32_t kStagesPerBlock = 2 * 4;  // double-buffered, four waves per 256-thread workgroup
+
+// Asynchronous global -> LDS copies (gfx950 LDS-DMA: no VGPR destination).  The LDS destination of one wave-instruction is
+// lds_base + lane * size, so both images are lane-linear.
+typedef const void __attribute__((address_space(1)))* vx_gptr;
+typedef void __attribute__((address_space(3)))* vx_lptr;
+__device__ __forceinline__ void stage_issue(UnitStage& S, const TriRec* __restrict__ recs, const uint32_t* __restrict__ unit_base, uint32_t t_lo, uint32_t n,
+                                            uint32_t lane)
+{
+    if (lane < n)  // n <= 64 bases (the search never reads base[n]): one 4-byte piece per lane
+        __builtin_amdgcn_global_load_lds((vx_gptr)(unit_base + t_lo + lane), (vx_lptr)&S.base[0], 4, 0, 0);
+    const float4* src = reinterpret_cast<const float4*>(recs + t_lo);
+#pragma unroll
+    for (uint32_t k = 0; k < 3u; ++k) {  // 3 n <= 192 sixteen-byte pieces
+        const uint32_t i = lane + k * 64u;
+        if (i < n * 3u) __builtin_amdgcn_global_load_lds((vx_gptr)(src + i), (vx_lptr)&S.rec[k * 64u], 16, 0, 0);
+    }
+}
+
+// Calls f(u, triangle, record, u - unit_base[triangle]) for every work unit, one unit per lane, 64 per wave pass.  Each
+// wave works on its own: it stages through its own two LDS buffers and never meets a workgroup barrier, so a wave with a
+// long row (32 voxels, all axes) does not hold up its neighbours.  The staging is software-pipelined: a pass first reads
+// its lane's record out of the buffer that landed, THEN issues the LDS-DMA of the next pass into the other buffer and the
+// scalar loads of the range of the pass after it, and only then runs the functor -- so the one s_waitcnt vmcnt(0) at the top
+// of a pass finds the copies complete.  (The order matters: the compiler orders every LDS read after all LDS-DMA in flight,
+// whichever buffer it targets, and a range load that feeds arithmetic is waited for where the arithmetic stands.)
 template <class F>
 __device__ __forceinline__ void for_each_unit(const TriRec* __restrict__ recs, const uint32_t* __restrict__ unit_base,
-                                              const uint32_t* __restrict__ block_tri, uint32_t ntri, UnitStage& S, F&& f)
+                                              const uint32_t* __restrict__ block_tri, uint32_t ntri, UnitStage* stages /*[kStagesPerBlock]*/, F&& f)
 {
     const uint32_t U = unit_base[ntri];
-    const uint32_t nUB = (U + 255u) >> 8;
-    for (uint32_t ub = blockIdx.x; ub < nUB; ub += gridDim.x) {
-        const uint32_t u = (ub << 8) + threadIdx.x;
-        uint32_t t_lo = 0, n = 0xFFFFFFFFu;
+    const uint32_t nUB = (U + 63u) >> kUnitBlockLog2;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: the range loads go scalar
+    const uint32_t stride = gridDim.x * (blockDim.x >> 6);
+    // consecutive waves of the machine take consecutive blocks: neighbours share record cache lines
+    uint32_t ub = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (ub >= nUB) return;
+    UnitStage* S2 = stages + 2u * wave;
+#ifdef VX_VOX_DEBUG
+    unsigned long long vdbg[6] = {0, 0, 0, 0, 0, 0}, vlast = __builtin_readcyclecounter();
+#endif
+    // triangles [tlo, thi] own the units of pass b (without block_tri: thi - tlo is "too many": global search)
+    auto range = [&](uint32_t b, uint32_t& tlo, uint32_t& thi) {
+        tlo = 0u;
+        thi = 0xFFFFFFF0u;
         if (block_tri) {
-            t_lo = block_tri[ub];
-            const uint32_t t_hi = (ub + 1 < nUB) ? block_tri[ub + 1] : ntri - 1;
-            n = t_hi - t_lo + 1;
+            tlo = block_tri[b];
+            thi = (b + 1 < nUB) ? block_tri[b + 1] : ntri - 1;
         }
-        const bool staged = n <= kStageTris;  // workgroup-uniform
-        if (staged) {
-            for (uint32_t i = threadIdx.x; i <= n; i += 256u) S.base[i] = unit_base[t_lo + i];
-            const float4* src = reinterpret_cast<const float4*>(recs + t_lo);
-            for (uint32_t i = threadIdx.x; i < n * 3u; i += 256u) S.rec[i] = src[i];
-            __syncthreads();
-        }
+    };
+    uint32_t t_lo, t_hi, t_lo_n = 0u, t_hi_n = 0u;
+    range(ub, t_lo, t_hi);
+    if (t_hi - t_lo < kStageTris) stage_issue(S2[0], recs, unit_base, t_lo, t_hi - t_lo + 1u, lane);
+    uint32_t ubn = ub + stride;
+    if (ubn < nUB) range(ubn, t_lo_n, t_hi_n);
+    int cur = 0;
+    for (;;) {
+        // this pass's staging (issued one pass ago by this wave) has landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        VX_V_T(4)
+        const UnitStage& S = S2[cur];
+        const uint32_t u = (ub << kUnitBlockLog2) + lane;
+        const uint32_t n = t_hi - t_lo + 1u;
+        const bool staged = t_hi - t_lo < kStageTris;
+        uint32_t tri = 0, rel = 0;
+        TriRec r;
         if (u < U) {
             if (staged) {
                 uint32_t lo = 0, hi = n;  // S.base[lo] <= u < S.base[hi]
@@ -631,20 +686,37 @@ __device__ __forceinline__ void for_each_unit(const TriRec* __restrict__ recs, c
                     if (S.base[mid] <= u) lo = mid; else hi = mid;
                 }
                 const float4 a = S.rec[lo * 3], b = S.rec[lo * 3 + 1], c = S.rec[lo * 3 + 2];
-                TriRec r;
                 r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
                 r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
                 r.v[8] = c.x;
                 r.xr = __float_as_uint(c.y); r.yr = __float_as_uint(c.z); r.zr = __float_as_uint(c.w);
-                f(u, t_lo + lo, r, u - S.base[lo]);
+                rel = u - S.base[lo];
+                tri = t_lo + lo;
             } else {
-                const uint32_t t = find_tri(unit_base, ntri, u);
-                const TriRec r = load_rec(recs, t);
-                f(u, t, r, u - unit_base[t]);
+                tri = find_tri(unit_base, ntri, u);
+                r = load_rec(recs, tri);
+                rel = u - unit_base[tri];
             }
         }
-        if (staged) __syncthreads();
+        VX_V_T(1)
+        const uint32_t ubnn = ubn + stride;
+        uint32_t t_lo_nn = 0u, t_hi_nn = 0u;
+        if (ubn < nUB) {
+            if (t_hi_n - t_lo_n < kStageTris) stage_issue(S2[cur ^ 1], recs, unit_base, t_lo_n, t_hi_n - t_lo_n + 1u, lane);
+            if (ubnn < nUB) range(ubnn, t_lo_nn, t_hi_nn);
+        }
+        VX_V_T(0)
+        if (u < U) f(u, tri, r, rel);
+        VX_V_T(2)
+        if (ubn >= nUB) break;
+        ub = ubn; ubn = ubnn;
+        t_lo = t_lo_n; t_hi = t_hi_n;
+        t_lo_n = t_lo_nn; t_hi_n = t_hi_nn;
+        cur ^= 1;
     }
+#ifdef VX_VOX_DEBUG
+    if (lane == 0) for (int i = 0; i < 6; ++i) atomicAdd(&g_vox_dbg[i], vdbg[i]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -657,7 +729,7 @@ __global__ __launch_bounds__(256) void k_voxelize(const TriRec* __restrict__ rec
                                                   const uint32_t* __restrict__ block_tri, uint32_t ntri, GridParams g, uint32_t* __restrict__ words,
                                                   uint64_t wb, uint64_t we, uint32_t* __restrict__ unit_mask, unsigned long long* set_calls)
 {
-    __shared__ UnitStage stage;
+    __shared__ UnitStage stage[kStagesPerBlock];
     unsigned hits = 0;
     for_each_unit(recs, unit_base, block_tri, ntri, stage, [&](uint32_t u, uint32_t t, const TriRec& r, uint32_t rel) {
         const Unit w = decode_unit(r, t, rel);
@@ -670,21 +742,46 @@ __global__ __launch_bounds__(256) void k_voxelize(const TriRec* __restrict__ rec
         if (row.alive) {
 #endif
             // (a two-sweep form -- box x + plane on every voxel, the six edge axes on the survivors only -- is slower: the
-            // wave pays for its lane with the most survivors, 0.21 ms vs 0.18 ms)
+            // wave pays for its lane with the most survivors, 0.21 ms vs 0.18 ms; unrolled by two, the sweep needs twice the
+            // registers for no gain)
+#pragma clang loop unroll(disable) vectorize(disable)
             for (uint32_t x = w.x0; x < w.x1; ++x) {
                 const float cx = cell_centre(g.org[0], g.vs, x);
                 if (sat_row_test<EPS>(row, r.v, cx, g.half)) mask |= 1u << (x & 31u);
             }
         }
         if (STORE_MASK) unit_mask[u] = mask;
+#ifdef VX_VOX_DEBUG  // [6] lanes of a wave pass that have bits to set, [7] distinct first words among them
+        {
+            const unsigned long long act = __ballot(mask != 0);
+            const uint32_t key = (uint32_t)(((uint64_t)g.dim[0] * ((uint64_t)w.y + (uint64_t)g.dim[1] * w.z) + w.xseg) >> 5);
+            unsigned distinct = 0;
+            unsigned long long rem = act;
+            while (rem) {
+                const int l = __ffsll((long long)rem) - 1;
+                const uint32_t k = __shfl(key, l, 64);
+                rem &= ~__ballot(key == k);
+                ++distinct;
+            }
+            if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) {
+                atomicAdd(&g_vox_dbg[6], (unsigned long long)__popcll(act));
+                atomicAdd(&g_vox_dbg[7], (unsigned long long)distinct);
+            }
+        }
+#endif
         if (mask) {
             const uint64_t i0 = (uint64_t)g.dim[0] * ((uint64_t)w.y + (uint64_t)g.dim[1] * w.z) + w.xseg;  // map3dto1d, voxelgrid.hpp:37-40
             const uint32_t sh = (uint32_t)i0 & 31u;
             const uint64_t wi = i0 >> 5;
             const uint32_t lo = mask << sh;
             const uint32_t hi = sh ? (mask >> (32u - sh)) : 0u;
+            // The atomics execute at the memory side, one 64-byte request per lane whatever the wave's address pattern: their
+            // request rate (about 20 G/s for the chip), not the SAT, bounds this kernel.
 #ifdef VX_DIAG_NO_ATOMICS  // diagnostic build: price of the atomics (results are wrong)
             hits += __popc(lo) + __popc(hi);
+#elif defined(VX_DIAG_PLAIN_STORE)  // diagnostic build: the same addresses by plain stores (results are wrong)
+            if (lo && wi >= wb && wi < we) { words[wi] = lo; hits += __popc(lo); }
+            if (hi && wi + 1 >= wb && wi + 1 < we) { words[wi + 1] = hi; hits += __popc(hi); }
 #else
             if (lo && wi >= wb && wi < we) { atomicOr(&words[wi], lo); hits += __popc(lo); }        // voxelgridBool.cpp:66
             if (hi && wi + 1 >= wb && wi + 1 < we) { atomicOr(&words[wi + 1], hi); hits += __popc(hi); }
@@ -696,6 +793,17 @@ __global__ __launch_bounds__(256) void k_voxelize(const TriRec* __restrict__ rec
     if ((threadIdx.x & 63) == 0 && hits) atomicAdd(set_calls, (unsigned long long)hits);
 #endif
 }
+
+#ifdef VX_VOX_DEBUG
+}  // namespace vx
+extern "C" int vx_debug_vox(unsigned long long* out8, int reset)
+{
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(vx::g_vox_dbg), 8 * 8) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(vx::g_vox_dbg), z, 8 * 8) != hipSuccess) return 1; }
+    return 0;
+}
+namespace vx {
+#endif
 
 void launch_voxelize(const TriRec* recs, const uint32_t* unit_base, const uint32_t* block_tri, uint32_t ntri, const GridParams& g, int sat_variant,
                      uint32_t* words, uint64_t wb, uint64_t we, uint32_t* unit_mask, unsigned long long* set_calls, hipStream_t s)
@@ -721,7 +829,7 @@ __global__ __launch_bounds__(256) void k_emit_units(const TriRec* __restrict__ r
                                                     const uint32_t* __restrict__ unit_mask, const uint32_t* __restrict__ hit_base,
                                                     vx_aabb* __restrict__ aabbs, uint64_t* __restrict__ morton, uint64_t cap /*records the output can hold*/)
 {
-    __shared__ UnitStage stage;
+    __shared__ UnitStage stage[kStagesPerBlock];
     for_each_unit(recs, unit_base, block_tri, ntri, stage, [&](uint32_t u, uint32_t t, const TriRec& r, uint32_t rel) {
         uint32_t mask = unit_mask[u];
         if (!mask) return;
@@ -893,7 +1001,7 @@ __global__ __launch_bounds__(256) void k_mat_last(const TriRec* __restrict__ rec
                                                   const uint32_t* __restrict__ word_prefix, uint32_t* __restrict__ last_tri /*per occupied voxel, 0 = none yet*/,
                                                   uint8_t* __restrict__ tri_hit)
 {
-    __shared__ UnitStage stage;
+    __shared__ UnitStage stage[kStagesPerBlock];
     for_each_unit(recs, unit_base, block_tri, ntri, stage, [&](uint32_t u, uint32_t t, const TriRec& r, uint32_t rel) {
         uint32_t mask = unit_mask[u];
         if (!mask) return;
@@ -927,7 +1035,7 @@ __global__ __launch_bounds__(256) void k_mat_ids_calls(const TriRec* __restrict_
                                                        uint32_t ntri, const uint32_t* __restrict__ unit_mask, const uint32_t* __restrict__ hit_base,
                                                        const int32_t* __restrict__ tri_value, const int16_t* __restrict__ value_index, int16_t* __restrict__ out)
 {
-    __shared__ UnitStage stage;
+    __shared__ UnitStage stage[kStagesPerBlock];
     for_each_unit(recs, unit_base, block_tri, ntri, stage, [&](uint32_t u, uint32_t t, const TriRec&, uint32_t) {
         const uint32_t n = __popc(unit_mask[u]);
         if (!n) return;
