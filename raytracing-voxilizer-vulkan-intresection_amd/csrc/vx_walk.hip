@@ -362,11 +362,18 @@ __device__ __forceinline__ WalkColdPtr walk_cold()
     return (WalkColdPtr)(p + offsetof(WalkParams, cold));
 }
 
+#if defined(VX_W_DEBUG) && !defined(VX_W_TS)
+#define VX_W_TS
+#endif
+#ifdef VX_W_TS
+__device__ unsigned long long g_walk_ts[3 * 8192];  // per wave: s_memtime at entry, when its queue ran dry, at exit
+#endif
 #ifdef VX_W_DEBUG
 // diagnostic build: lane utilisation per code site.  site i: g_walk_dbg[2i] = times a wave executed the site, [2i+1] = lanes active
 // over those executions.  Sites: 0 ray set-up, 1 mip lookup, 2 slab step, 3 brick, 4 candidate slab, 5 exact test, 6 retire, 7 round
 // (lanes busy); [16..19] wave cycles in refill / walk / brick / retire.
 __device__ unsigned long long g_walk_dbg[24];
+__device__ unsigned long long g_walk_hist[2 * 16];  // rays by slab steps (bucket b: [2^b, 2^(b+1)) steps; bucket 0 also holds 0), and the steps they took
 #define VX_W_SITE(i) { const unsigned long long m_ = __ballot(true); if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) { dbg_w[i] += 1u; dbg_l[i] += (unsigned)__popcll(m_); } }
 #define VX_W_SITE_DECL , unsigned* dbg_w, unsigned* dbg_l
 #define VX_W_SITE_ARGS , dbg_w, dbg_l
@@ -463,7 +470,7 @@ __device__ __forceinline__ void walk_fetch_brick(WalkLane<IdxT>& R, const WalkHo
 // (level 0).  All three share the slab's [ta, tb], the termination test and the rectangle of cells; they differ in what the
 // rectangle is looked up in.  Returns false when the ray is finished.
 template <bool LDS_MIPS, typename IdxT>
-__device__ __forceinline__ bool walk_step(WalkLane<IdxT>& R, const WalkHot& P, const uint32_t* __restrict__ mips_lds VX_W_SITE_DECL)
+__device__ __forceinline__ bool walk_step(WalkLane<IdxT>& R, const WalkHot& P, const uint32_t* __restrict__ mips_lds, bool& xpend, uint4* __restrict__ xslot VX_W_SITE_DECL)
 {
     VX_W_SITE(2)
     const GridParams& g = P.g;
@@ -516,32 +523,11 @@ __device__ __forceinline__ bool walk_step(WalkLane<IdxT>& R, const WalkHot& P, c
                 cand = bits & col & (~0ull >> (8 * (7 - b1))) & (~0ull << (8 * b0));
             }
             if (cand) {
-                // the slab's own box planes along w (voxelgridBool.cpp:37-41: c -/+ half with c = org + (i + 0.5) * vs) and their hitAabb terms
-                const float cw = R.orgw + (((float)k + 0.5f) * g.vs);
-                const float bw = R.iw * ((cw - g.half) - R.ow), tw = R.iw * ((cw + g.half) - R.ow);
-                const float mnw = fminf(tw, bw), mxw = fmaxf(tw, bw);
-                while (cand) {
-                    VX_W_SITE(5)
-                    const int b = __ffsll((long long)cand) - 1;
-                    cand &= cand - 1ull;
-                    const int cu_ = bu + (b & 7), cv_ = bv + (b >> 3);
-                    const float ccu = R.orgu + (((float)cu_ + 0.5f) * g.vs), ccv = R.orgv + (((float)cv_ + 0.5f) * g.vs);
-                    const float bu_ = R.iu * ((ccu - g.half) - R.ou), tu_ = R.iu * ((ccu + g.half) - R.ou);
-                    const float bv_ = R.iv * ((ccv - g.half) - R.ov), tv_ = R.iv * ((ccv + g.half) - R.ov);
-                    // hitAabb, rint:46-56: t0 = max of the per-axis minima, t1 = min of the per-axis maxima (any axis order: same floats)
-                    const float t0 = fmaxf(fmaxf(fminf(tu_, bu_), fminf(tv_, bv_)), mnw);
-                    const float t1 = fminf(fminf(fmaxf(tu_, bu_), fmaxf(tv_, bv_)), mxw);
-                    const float t = t1 > fmaxf(t0, 0.0f) ? t0 : -1.0f;
-                    int cx, cy, cz;
-                    unperm(R.perm, cu_, cv_, k, cx, cy, cz);
-                    const IdxT vi = (IdxT)(uint32_t)cx + (IdxT)g.dim[0] * ((IdxT)(uint32_t)cy + (IdxT)g.dim[1] * (IdxT)(uint32_t)cz);
-                    if (t > 0.0f && t >= P.tmin && t <= R.tmax &&                 // rint:69, rgen:50-51
-                        (t < R.best || (t == R.best && vi < R.best_idx))) {
-                        R.best = t;
-                        R.best_idx = vi;
-                    }
-                }
-                if (P.any_hit && R.best_idx != (IdxT)~(IdxT)0) return false;  // shadow query (gl_RayFlagsTerminateOnFirstHitEXT, raytrace2.rchit:108)
+                // The exact tests are not done here, where one lane in sixteen has candidates: the lane parks them in its LDS slot
+                // and sits out the rest of the round; all parked lanes of the wave test together at the end of the round (walk_exact).
+                // Until then the lane's best hit is stale, which only postpones the pruning that depends on it.
+                *xslot = make_uint4((uint32_t)cand, (uint32_t)(cand >> 32), (uint32_t)k, R.pc);
+                xpend = true;
             }
         } else {
             const bool top = lvl == 2;
@@ -554,19 +540,44 @@ __device__ __forceinline__ bool walk_step(WalkLane<IdxT>& R, const WalkHot& P, c
             // comparable to a brick (coordinates of ~10^6 voxel sizes, where float32 no longer resolves the voxels anyway); the
             // window logic only keeps that regime correct, not fast.
             const int jb = R.jb;
-            int ju = jb, jv = 0;
-            while (ju >= nu && nu > 0) { ju -= nu; ++jv; }
-            const int jend = n < jb + 16 ? n : jb + 16;
             uint32_t occ = 0u;  // bit j - jb: cell (cu0 + j % nu, cv0 + j / nu) of the rectangle is occupied
-#pragma nounroll
-            for (int j = jb; j < jend; ++j) {
+            int jend;
+            if (jb == 0 && nu <= 2 && nv <= 2) {
+                // The rule -- a rectangle of at most 2 x 2 cells: its four look-ups side by side instead of a loop that every lane
+                // of the wave sits through for as many turns as the largest rectangle among them needs.  A cell the rectangle does
+                // not have reads the first cell's word again and is masked out.
                 VX_W_SITE(1)
+                jend = n;
                 int x, y, z;
-                unperm(R.perm, cu0 + ju, cv0 + jv, k, x, y, z);
-                const uint32_t i = (uint32_t)x + Dx * ((uint32_t)y + Dy * (uint32_t)z);
-                const uint32_t wd = LDS_MIPS ? mips_lds[moff + (i >> 5)] : (top ? P.w2[i >> 5] : P.w1[i >> 5]);
-                occ |= ((wd >> (i & 31u)) & 1u) << (j - jb);
-                if (++ju == nu) { ju = 0; ++jv; }
+                unperm(R.perm, cu0, cv0, k, x, y, z);
+                const uint32_t i00 = n > 0 ? (uint32_t)x + Dx * ((uint32_t)y + Dy * (uint32_t)z) : 0u;  // (an empty rectangle may lie outside the grid)
+                // linear-index strides of one cell along u and along v:  w=0: u=y v=z;  w=1: u=z v=x;  w=2: u=x v=y
+                const uint32_t su = R.perm == 0 ? Dx : (R.perm == 1 ? Dx * Dy : 1u), sv = R.perm == 0 ? Dx * Dy : (R.perm == 1 ? 1u : Dx);
+                const bool hu = nu == 2, hv = nv == 2;
+                const uint32_t i10 = hu ? i00 + su : i00, i01 = hv ? i00 + sv : i00, i11 = (hu && hv) ? i00 + su + sv : i00;
+                uint32_t w00, w10, w01, w11;
+                if (LDS_MIPS) {
+                    w00 = mips_lds[moff + (i00 >> 5)]; w10 = mips_lds[moff + (i10 >> 5)]; w01 = mips_lds[moff + (i01 >> 5)]; w11 = mips_lds[moff + (i11 >> 5)];
+                } else {
+                    const uint32_t* __restrict__ mp = top ? P.w2 : P.w1;
+                    w00 = mp[i00 >> 5]; w10 = mp[i10 >> 5]; w01 = mp[i01 >> 5]; w11 = mp[i11 >> 5];
+                }
+                const uint32_t b00 = (w00 >> (i00 & 31u)) & 1u, b10 = (w10 >> (i10 & 31u)) & 1u, b01 = (w01 >> (i01 & 31u)) & 1u, b11 = (w11 >> (i11 & 31u)) & 1u;
+                if (n > 0) occ = b00 | (hu ? b10 << 1 : 0u) | (hv ? b01 << nu : 0u) | ((hu && hv) ? b11 << 3 : 0u);
+            } else {
+                int ju = jb, jv = 0;
+                while (ju >= nu && nu > 0) { ju -= nu; ++jv; }
+                jend = n < jb + 16 ? n : jb + 16;
+#pragma nounroll
+                for (int j = jb; j < jend; ++j) {
+                    VX_W_SITE(1)
+                    int x, y, z;
+                    unperm(R.perm, cu0 + ju, cv0 + jv, k, x, y, z);
+                    const uint32_t i = (uint32_t)x + Dx * ((uint32_t)y + Dy * (uint32_t)z);
+                    const uint32_t wd = LDS_MIPS ? mips_lds[moff + (i >> 5)] : (top ? P.w2[i >> 5] : P.w1[i >> 5]);
+                    occ |= ((wd >> (i & 31u)) & 1u) << (j - jb);
+                    if (++ju == nu) { ju = 0; ++jv; }
+                }
             }
             const bool more = jend < n;
             if (occ) {
@@ -628,6 +639,42 @@ __device__ __forceinline__ bool walk_step(WalkLane<IdxT>& R, const WalkHot& P, c
     return walk_advance(R);
 }
 
+// The exact tests of the candidates a lane parked in its LDS slot: hitAabb on every candidate cell of one 1-cell slab of a brick.
+template <typename IdxT>
+__device__ __forceinline__ void walk_exact(WalkLane<IdxT>& R, const WalkHot& P, const uint4* __restrict__ xslot VX_W_SITE_DECL)
+{
+    const GridParams& g = P.g;
+    const uint4 xs = *xslot;
+    unsigned long long cand = (unsigned long long)xs.x | ((unsigned long long)xs.y << 32);
+    const int k = (int)xs.z;
+    const int bu = (int)(xs.w & 0xFFFFu) << 3, bv = (int)(xs.w >> 16) << 3;
+    // the slab's own box planes along w (voxelgridBool.cpp:37-41: c -/+ half with c = org + (i + 0.5) * vs) and their hitAabb terms
+    const float cw = R.orgw + (((float)k + 0.5f) * g.vs);
+    const float bw = R.iw * ((cw - g.half) - R.ow), tw = R.iw * ((cw + g.half) - R.ow);
+    const float mnw = fminf(tw, bw), mxw = fmaxf(tw, bw);
+    while (cand) {
+        VX_W_SITE(5)
+        const int b = __ffsll((long long)cand) - 1;
+        cand &= cand - 1ull;
+        const int cu_ = bu + (b & 7), cv_ = bv + (b >> 3);
+        const float ccu = R.orgu + (((float)cu_ + 0.5f) * g.vs), ccv = R.orgv + (((float)cv_ + 0.5f) * g.vs);
+        const float bu_ = R.iu * ((ccu - g.half) - R.ou), tu_ = R.iu * ((ccu + g.half) - R.ou);
+        const float bv_ = R.iv * ((ccv - g.half) - R.ov), tv_ = R.iv * ((ccv + g.half) - R.ov);
+        // hitAabb, rint:46-56: t0 = max of the per-axis minima, t1 = min of the per-axis maxima (any axis order: same floats)
+        const float t0 = fmaxf(fmaxf(fminf(tu_, bu_), fminf(tv_, bv_)), mnw);
+        const float t1 = fminf(fminf(fmaxf(tu_, bu_), fmaxf(tv_, bv_)), mxw);
+        const float t = t1 > fmaxf(t0, 0.0f) ? t0 : -1.0f;
+        int cx, cy, cz;
+        unperm(R.perm, cu_, cv_, k, cx, cy, cz);
+        const IdxT vi = (IdxT)(uint32_t)cx + (IdxT)g.dim[0] * ((IdxT)(uint32_t)cy + (IdxT)g.dim[1] * (IdxT)(uint32_t)cz);
+        if (t > 0.0f && t >= P.tmin && t <= R.tmax &&                 // rint:69, rgen:50-51
+            (t < R.best || (t == R.best && vi < R.best_idx))) {
+            R.best = t;
+            R.best_idx = vi;
+        }
+    }
+}
+
 // position of the n-th (0-based) set bit of a 64-bit mask (n < popcount)
 __device__ __forceinline__ int nth_set_bit64_w(unsigned long long m, int n)
 {
@@ -672,6 +719,8 @@ __global__ __launch_bounds__(VX_W_BLOCK, VX_W_MINWAVES) void k_walk(const WalkPa
     constexpr float kDonateBricks = VX_W_DON_BRICKS;  // ... and only from pieces with more than this many brick slabs left
     __shared__ unsigned long long don_key[VX_W_BLOCK];
     __shared__ unsigned don_cnt[VX_W_BLOCK];
+    __shared__ uint4 xslots[VX_W_BLOCK];  // per lane: the candidate cells parked for the round's exact-test phase
+    bool xpend = false;
     const int lane = threadIdx.x & 63;
     int slot = -1;             // >= 0: this lane walks a PIECE of a split ray; its result goes through don_key[slot]
     WalkLane<IdxT> R;
@@ -679,6 +728,11 @@ __global__ __launch_bounds__(VX_W_BLOCK, VX_W_MINWAVES) void k_walk(const WalkPa
 #ifdef VX_W_DEBUG
     unsigned dbg_w[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbg_l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long dbg_c[4] = {0, 0, 0, 0}, dbg_last = __builtin_readcyclecounter();
+    unsigned dbg_steps = 0;
+#endif
+#ifdef VX_W_TS
+    const unsigned long long ts_begin = __builtin_readcyclecounter();
+    unsigned long long ts_drained = 0;
 #endif
     uint32_t r = 0xFFFFFFFFu;  // ray this lane is tracing
     bool busy = false;         // traversal in progress
@@ -729,6 +783,9 @@ __global__ __launch_bounds__(VX_W_BLOCK, VX_W_MINWAVES) void k_walk(const WalkPa
                 if (base + csz >= nrays) drained_global = true;
             }
             if (drained_global && chunk_cur >= chunk_end) drained = true;
+#ifdef VX_W_TS
+            if (drained && !ts_drained) ts_drained = __builtin_readcyclecounter();
+#endif
             if (!busy) {
                 const uint32_t posn = (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
                 uint32_t mine = 0xFFFFFFFFu;
@@ -825,9 +882,20 @@ __global__ __launch_bounds__(VX_W_BLOCK, VX_W_MINWAVES) void k_walk(const WalkPa
         // ---- walk: every busy lane advances by one slab per step, whatever its level
         bool finished = false;
         for (int s = 0; s < kStepsPerRound * kItersPerRound; ++s) {
-            const bool go = busy && !finished;
+            const bool go = busy && !finished && !xpend;
             if (!__ballot(go)) break;
-            if (go && !walk_step<LDS_MIPS>(R, P, mips_lds VX_W_SITE_ARGS)) finished = true;
+#ifdef VX_W_DEBUG
+            if (go) ++dbg_steps;
+#endif
+            if (go && !walk_step<LDS_MIPS>(R, P, mips_lds, xpend, &xslots[threadIdx.x] VX_W_SITE_ARGS)) finished = true;
+        }
+        // ---- exact tests of the candidates the steps parked
+        if (__ballot(xpend)) {
+            if (xpend) {
+                walk_exact(R, P, &xslots[threadIdx.x] VX_W_SITE_ARGS);
+                xpend = false;
+                if (P.any_hit && R.best_idx != (IdxT)~(IdxT)0) finished = true;  // shadow query (gl_RayFlagsTerminateOnFirstHitEXT, raytrace2.rchit:108)
+            }
         }
         VX_W_T(1)
         // ---- retire: t and the voxel index of the hit; the primitive rank (two dependent loads), the normal and the hit
@@ -836,6 +904,14 @@ __global__ __launch_bounds__(VX_W_BLOCK, VX_W_MINWAVES) void k_walk(const WalkPa
             const WalkColdPtr C = walk_cold();
             if (finished) {
                 VX_W_SITE(6)
+#ifdef VX_W_DEBUG
+                {
+                    const int bk = dbg_steps ? 31 - __clz(dbg_steps) : 0;
+                    atomicAdd(&g_walk_hist[bk < 15 ? bk : 15], 1ull);
+                    atomicAdd(&g_walk_hist[16 + (bk < 15 ? bk : 15)], (unsigned long long)dbg_steps);
+                    dbg_steps = 0;
+                }
+#endif
                 bool hit = R.best_idx != (IdxT)~(IdxT)0;
                 float best_t = R.best;
                 IdxT best_i = R.best_idx;
@@ -874,6 +950,12 @@ __global__ __launch_bounds__(VX_W_BLOCK, VX_W_MINWAVES) void k_walk(const WalkPa
     }
     if (lane == 0) for (int i = 0; i < 4; ++i) atomicAdd(&g_walk_dbg[16 + i], dbg_c[i]);
 #endif
+#ifdef VX_W_TS
+    {
+        const uint32_t wid = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+        if (lane == 0 && wid < 8192u) { g_walk_ts[3 * wid] = ts_begin; g_walk_ts[3 * wid + 1] = ts_drained; g_walk_ts[3 * wid + 2] = __builtin_readcyclecounter(); }
+    }
+#endif
 }
 
 #ifdef VX_W_DEBUG
@@ -883,6 +965,21 @@ extern "C" int vx_debug_walk(unsigned long long* out24, int reset)
     if (out24 && hipMemcpyFromSymbol(out24, HIP_SYMBOL(vx::g_walk_dbg), 24 * 8) != hipSuccess) return 1;
     if (reset) { unsigned long long z[24] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(vx::g_walk_dbg), z, 24 * 8) != hipSuccess) return 1; }
     return 0;
+}
+extern "C" int vx_debug_walk_hist(unsigned long long* out32, int reset)
+{
+    if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(vx::g_walk_hist), 32 * 8) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[32] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(vx::g_walk_hist), z, 32 * 8) != hipSuccess) return 1; }
+    return 0;
+}
+
+namespace vx {
+#endif
+#ifdef VX_W_TS
+}  // namespace vx
+extern "C" int vx_debug_walk_ts(unsigned long long* out /*[3 * 8192]*/)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(vx::g_walk_ts), 3 * 8192 * 8) == hipSuccess ? 0 : 1;
 }
 namespace vx {
 #endif
@@ -925,7 +1022,13 @@ void launch_walk(const GridParams& g, const TraceMips& mips, const TraceIO& io, 
         P.hot.nrays = (uint32_t)n;
         P.cold.ray_base = base;
         (void)hipMemsetAsync(counter, 0, sizeof(unsigned long long), s);
-        const uint64_t max_blocks = env_blocks > 0 ? (uint64_t)env_blocks : 256ull * VX_W_MINWAVES * 4ull * 64ull / VX_W_BLOCK;  // one resident set of waves
+        uint64_t max_blocks = 256ull * VX_W_MINWAVES * 4ull * 64ull / VX_W_BLOCK;  // one resident set of waves
+        // Batches of a few rays per lane: the launch ends with every wave draining the rays it started last, a span of about two mean
+        // ray latencies whatever the batch; with somewhat fewer waves a lane sees at least ~4 rays and the same work drains from fewer
+        // rays in flight (measured on the bench scene, 0.5M / 0.75M / 1M rays: -3 / -8 / -8 %; below ~0.4M rays, where a lane has at
+        // most one or two rays anyway, the full width is faster, and from ~1.1M rays on the rule gives the full width).
+        if (n >= 400000ull && n / 1075ull < max_blocks) max_blocks = n / 1075ull;
+        if (env_blocks > 0) max_blocks = (uint64_t)env_blocks;
         uint64_t nblk = (n + VX_W_BLOCK - 1) / VX_W_BLOCK;
         if (nblk > max_blocks) nblk = max_blocks;
         const dim3 grid((unsigned)nblk), block(VX_W_BLOCK);

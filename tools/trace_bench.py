@@ -10,7 +10,7 @@ v, t = vx_scenes.scene("atrium262k")
 vs = np.float32(32.0 / grid)
 g = voxhip.Grid.voxelize(voxhip.Mesh.from_arrays(v, t), vs)
 out = []
-sizes = [int(x) * 1_000_000 for x in os.environ.get('TB_SIZES', '1,8').split(',')]
+sizes = [int(float(x) * 1_000_000) for x in os.environ.get('TB_SIZES', '1,8').split(',')]
 for n in sizes:
     rays_h = vx_scenes.random_rays(n, v.min(0), v.max(0), seed=2)
     rays = torch.from_numpy(rays_h).cuda()
@@ -22,7 +22,7 @@ for n in sizes:
         g.trace_device(rays.data_ptr(), n, d_t.data_ptr(), d_p.data_ptr())
     torch.cuda.synchronize(); voxhip.profile_enable(False)
     k = voxhip.profile_read()
-    out.append("%dM: " % (n // 1_000_000) + " ".join("%s %.4f" % (nm, ms / c) for nm, (ms, c) in sorted(k.items())))
+    out.append("%gM: " % (n / 1_000_000) + " ".join("%s %.4f" % (nm, ms / c) for nm, (ms, c) in sorted(k.items())))
     if n == 1_000_000 and not os.environ.get("TB_NOCHECK"):
         import oracle
         ow, _, gi = oracle.build_bool(v, t, vs, threads=32)
