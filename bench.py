@@ -331,7 +331,7 @@ def main():
     gd = grid.describe()
     alg_bytes = {  # algorithmic bytes per launch
         "k_voxelize": 36 * T + 8 * ((N + 31) // 32),
-        "k_trace": 28 * R + 4 * ((N + 31) // 32),
+        "k_walk": 28 * R + 4 * ((N + 31) // 32),
         "k_emit_bool": 4 * ((N + 31) // 32) + 24 * gd["occupied"],
         "k_emit_units": 36 * T + 24 * gd["set_calls"],
     }
@@ -405,6 +405,16 @@ def main():
                              for k in alg_bytes if k in kern_all},
         "kernels_survey_pass": kernels, "roofline": roof, "roofline_issue": roof_issue, "cpu_baseline": cpu,
     }
+    # k_voxelize is bound by neither HBM bytes nor issue: its atomicOr lanes are executed at the memory side, one 64-byte request per
+    # lane (MI355X_MICROARCH.md, global atomics: ~1.3 TB/s of 64-byte requests chip-wide = ~20.3 G requests/s).  The request count of
+    # this workload comes from the -DVX_VOX_DEBUG counters (tools/vox_dbg.py), committed in profiles/.
+    atag, aj = load_profile_json("atomics")
+    if aj and a.scene == "atrium262k" and a.grid == 512 and world == 1 and "k_voxelize" in kern_all:
+        avg = kern_all["k_voxelize"][0] / max(kern_all["k_voxelize"][1], 1) * 1e-3
+        req = aj["k_voxelize"]["atomic_lane_requests_per_launch"]
+        out["kernel_rooflines"]["k_voxelize"].update({"bound": "memory-side atomic requests", "requests_per_launch": req,
+                                                      "achieved_Greq_per_s": round(req / avg / 1e9, 2), "peak_Greq_per_s": aj["peak_Greq_per_s"],
+                                                      "frac": round(req / avg / 1e9 / aj["peak_Greq_per_s"], 3), "source": "profiles/%s_atomics.json" % atag})
     if world > 1:
         out["rccl_world"] = dist.get_world_size()
         out["exchange"] = {"algo": exch.algo, "bytes_per_rank": int(exch.bytes_per_rank), "ms": round(float(stage_ms[1]), 4),
