@@ -67,6 +67,9 @@ def parse():
                     help="vec: VoxelGridVec build (BASELINE configs[2]); bool: VoxelGridBool build + K4 getAabbs (the app's default path)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; the driver's multi-GPU runs) or gloo (rehearsal)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses device 0")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal with one rank: initialise the process group and run the sharded build + exchange path at world size 1 "
+                         "(the only way to execute the RCCL calls on a one-GPU box)")
     return ap.parse_args()
 
 
@@ -151,9 +154,11 @@ def main():
     torch.cuda.set_device(local)
     voxhip.set_device(local)
     dist = None
-    if world > 1:
+    sharded = world > 1 or a.force_dist
+    if sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29571")
         if a.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
@@ -175,7 +180,7 @@ def main():
     d_prim = torch.empty(a.rays, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
 
-    kind = voxhip.GRID_VEC if (world == 1 and a.flavour == "vec") else voxhip.GRID_BOOL
+    kind = voxhip.GRID_VEC if (not sharded and a.flavour == "vec") else voxhip.GRID_BOOL
     grid = voxhip.Grid.voxelize(mesh, vs, kind)  # sizes the handle's buffers (untimed)
     desc = grid.describe()
     nwords = desc["num_words"]
@@ -186,7 +191,7 @@ def main():
     d_aabbs = torch.empty(cap * 6, dtype=torch.float32, device=dev)
     if kind == voxhip.GRID_VEC:
         grid.bind_aabbs_device(d_aabbs.data_ptr(), cap)   # the list is built in the consumer's buffer: getAabbs has nothing left to copy
-    exch = vx_dist.Exchange(nwords, rank, world, dev, dist) if world > 1 else None
+    exch = vx_dist.Exchange(nwords, rank, world, dev, dist) if sharded else None
 
     # stage boundaries: five events per timed step, all read AFTER the timed region (reading them per step needs a device
     # synchronize per step, i.e. ~50 us of idle GPU per 1 ms step that is not part of the workload)
@@ -197,13 +202,13 @@ def main():
         ev = ev_all[k] if timed else None
         if timed:
             ev[0].record()
-        if world == 1:
+        if not sharded:
             grid.revoxelize(mesh, vs)
         else:
             grid.revoxelize(mesh, vs, words=(wb, we))
         if timed:
             ev[1].record()
-        if world > 1:
+        if sharded:
             mask = torch.as_tensor(DevView(grid.bitmask_device_ptr(mutable=True), nwords), device=dev)
             exch.run(mask)
         if timed:
@@ -270,7 +275,7 @@ def main():
 
     # ---- BASELINE configs[3] beside the timed workload (N > 1): sharded build + exchange of the same scene at 1024^3
     c4 = None
-    if world > 1 and a.c4_grid and a.c4_grid != a.grid:
+    if sharded and a.c4_grid and a.c4_grid != a.grid:
         vs4 = np.float32(ext / a.c4_grid)
         g4 = voxhip.Grid.voxelize(mesh, vs4, voxhip.GRID_BOOL)
         d4 = g4.describe()
@@ -415,7 +420,7 @@ def main():
         out["kernel_rooflines"]["k_voxelize"].update({"bound": "memory-side atomic requests", "requests_per_launch": req,
                                                       "achieved_Greq_per_s": round(req / avg / 1e9, 2), "peak_Greq_per_s": aj["peak_Greq_per_s"],
                                                       "frac": round(req / avg / 1e9 / aj["peak_Greq_per_s"], 3), "source": "profiles/%s_atomics.json" % atag})
-    if world > 1:
+    if sharded:
         out["rccl_world"] = dist.get_world_size()
         out["exchange"] = {"algo": exch.algo, "bytes_per_rank": int(exch.bytes_per_rank), "ms": round(float(stage_ms[1]), 4),
                            "GBps_per_rank": round(exch.bytes_per_rank * (world - 1) / max(stage_ms[1], 1e-9) / 1e6, 2)}
