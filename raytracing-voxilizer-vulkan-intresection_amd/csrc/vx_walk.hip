@@ -71,9 +71,12 @@ __device__ __forceinline__ unsigned long long transpose8x8(unsigned long long x)
     return x;
 }
 
+// `m1` (optional; needs BX % 64 == 0 so that a workgroup's 64 bricks are two whole words of it): the level-1 mip, one bit per brick,
+// written from here -- and then EMPTY bricks are not stored at all (the walk never fetches a brick whose level-1 bit is clear):
+// on a surface scene that is three quarters of the 3 x N/8 bytes this kernel would write.
 __global__ __launch_bounds__(256) void k_build_bricks3(const uint32_t* __restrict__ words, uint32_t X, uint32_t Y, uint32_t Z, uint32_t BX, uint32_t BY,
                                                        uint32_t BZ, uint32_t chunks_x, uint64_t nwords, unsigned long long* __restrict__ bricks3,
-                                                       uint64_t ori_stride /*uint64 words per orientation*/)
+                                                       uint64_t ori_stride /*uint64 words per orientation*/, uint32_t* __restrict__ m1)
 {
     __shared__ uint32_t rows[64][17];              // [z*8 + y][32-voxel chunk of the 512]; padded against bank conflicts of the column reads
     __shared__ unsigned long long sz[64][9];       // [brick][z slab]: bit y*8 + x (padded)
@@ -84,6 +87,7 @@ __global__ __launch_bounds__(256) void k_build_bricks3(const uint32_t* __restric
         const uint32_t by = (uint32_t)(q % BY), bz = (uint32_t)(q / BY);
         const uint32_t x0 = cx * 512u;
         // ---- load: 64 rows x 16 words, four items per thread
+        uint32_t nonzero = 0u;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t item = (uint32_t)k * 256u + threadIdx.x;
@@ -100,9 +104,18 @@ __global__ __launch_bounds__(256) void k_build_bricks3(const uint32_t* __restric
                 if (nb < 32u) val &= (1u << nb) - 1u;
             }
             rows[r][j] = val;
+            nonzero |= val;
         }
-        __syncthreads();
-        // ---- z orientation: two (brick, slab) pairs per thread; kept in LDS for the transposes
+        if (m1) {
+            // an empty row of 64 bricks (most of them, on a surface scene): two zero words of the mip, nothing else
+            if (!__syncthreads_or(nonzero != 0u)) {
+                if (threadIdx.x < 2u) m1[((uint64_t)cx * 64u + (uint64_t)BX * ((uint64_t)by + (uint64_t)BY * bz)) / 32u + threadIdx.x] = 0u;
+                continue;
+            }
+        } else {
+            __syncthreads();
+        }
+        // ---- z orientation (bit y*8 + x per z slab): two (brick, slab) pairs per thread, into LDS
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const uint32_t item = (uint32_t)k * 256u + threadIdx.x;
@@ -112,23 +125,25 @@ __global__ __launch_bounds__(256) void k_build_bricks3(const uint32_t* __restric
 #pragma unroll
             for (uint32_t yy = 0; yy < 8u; ++yy) bits |= (unsigned long long)((rows[sl * 8u + yy][b >> 2] >> sh) & 0xFFu) << (yy * 8u);
             sz[b][sl] = bits;
-            const uint32_t bx = cx * 64u + b;
-            if (bx < BX) {
-                const uint64_t brick = (uint64_t)bx + (uint64_t)BX * ((uint64_t)by + (uint64_t)BY * bz);
-                bricks3[2ull * ori_stride + brick * 8ull + sl] = bits;
-            }
         }
         __syncthreads();
-        // ---- x and y orientations: thread = (brick, orientation, half of the slabs)
+        // ---- stores: thread = (brick, part); part 0,1: x slabs 0-3 / 4-7, part 2,3: y slabs 0-3 / 4-7, and every part two of the z slabs
         {
-            const uint32_t b = threadIdx.x & 63u, part = threadIdx.x >> 6;  // part 0,1: x slabs 0-3 / 4-7; part 2,3: y slabs 0-3 / 4-7
+            const uint32_t b = threadIdx.x & 63u, part = threadIdx.x >> 6;
             const uint32_t bx = cx * 64u + b;
             unsigned long long s[8];
             unsigned long long any = 0ull;
 #pragma unroll
             for (int z = 0; z < 8; ++z) { s[z] = sz[b][z]; any |= s[z]; }
-            if (bx < BX) {
-                const uint64_t brick = (uint64_t)bx + (uint64_t)BX * ((uint64_t)by + (uint64_t)BY * bz);
+            const uint64_t brick = (uint64_t)bx + (uint64_t)BX * ((uint64_t)by + (uint64_t)BY * bz);
+            if (m1 && part == 0u) {
+                const unsigned long long occ = __ballot(any != 0ull);  // BX % 64 == 0: all 64 bricks exist, `brick` of lane 0 is a multiple of 64
+                if (b == 0u) {
+                    m1[brick >> 5] = (uint32_t)occ;
+                    m1[(brick >> 5) + 1u] = (uint32_t)(occ >> 32);
+                }
+            }
+            if (bx < BX && (any || !m1)) {
                 const uint32_t ori = part >> 1, s0 = (part & 1u) * 4u;
                 unsigned long long* dst = bricks3 + (uint64_t)ori * ori_stride + brick * 8ull + s0;
                 unsigned long long out[4] = {0ull, 0ull, 0ull, 0ull};
@@ -152,25 +167,33 @@ __global__ __launch_bounds__(256) void k_build_bricks3(const uint32_t* __restric
                         }
                     }
                 }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) dst[j] = out[j];
+                reinterpret_cast<ulonglong2*>(dst)[0] = make_ulonglong2(out[0], out[1]);
+                reinterpret_cast<ulonglong2*>(dst)[1] = make_ulonglong2(out[2], out[3]);
+                unsigned long long* dz = bricks3 + 2ull * ori_stride + brick * 8ull + 2u * part;
+                const unsigned long long z0 = part == 0u ? s[0] : (part == 1u ? s[2] : (part == 2u ? s[4] : s[6]));
+                const unsigned long long z1 = part == 0u ? s[1] : (part == 1u ? s[3] : (part == 2u ? s[5] : s[7]));
+                *reinterpret_cast<ulonglong2*>(dz) = make_ulonglong2(z0, z1);
             }
         }
         __syncthreads();
     }
 }
 
-void launch_build_bricks3(const uint32_t* words, const uint32_t dim[3], const uint32_t bdim[3], unsigned long long* bricks3, hipStream_t s)
+// Returns true when the level-1 mip was written by the brick kernel itself (and empty bricks were left unwritten).
+bool launch_build_bricks3(const uint32_t* words, const uint32_t dim[3], const uint32_t bdim[3], unsigned long long* bricks3, uint32_t* m1, hipStream_t s)
 {
     const uint64_t n = (uint64_t)bdim[0] * bdim[1] * bdim[2];
-    if (!n) return;
+    if (!n) return false;
     const uint32_t chunks_x = (bdim[0] + 63u) / 64u;
     const uint64_t ngroups = (uint64_t)chunks_x * bdim[1] * bdim[2];
     const uint64_t nvox = (uint64_t)dim[0] * dim[1] * dim[2];
     const uint64_t nwords = (nvox + 31) / 32;
     uint64_t nblk = ngroups;
     if (nblk > 16384) nblk = 16384;
-    VX_KL(k_build_bricks3, dim3((unsigned)nblk), dim3(256), 0, s, words, dim[0], dim[1], dim[2], bdim[0], bdim[1], bdim[2], chunks_x, nwords, bricks3, n * 8ull);
+    const bool fused = (bdim[0] % 64u) == 0u && m1 != nullptr;
+    VX_KL(k_build_bricks3, dim3((unsigned)nblk), dim3(256), 0, s, words, dim[0], dim[1], dim[2], bdim[0], bdim[1], bdim[2], chunks_x, nwords, bricks3, n * 8ull,
+          fused ? m1 : nullptr);
+    return fused;
 }
 
 namespace {
