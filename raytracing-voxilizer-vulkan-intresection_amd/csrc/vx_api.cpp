@@ -171,7 +171,7 @@ vx_status need_device(int dev)
 struct Small {
     unsigned long long bbox_state[8];  // K1's self-cleaning reduction state (initialised once, see ensure_small)
     vx::DevGrid dgrid;                 // origin + dims as K1 derives them, for kernels queued before the host has seen the bbox
-    unsigned long long set_calls;
+    unsigned long long set_calls[vx::kCallCounters * 8];  // 64 counters on lines of their own (k_voxelize), summed by sync_counts
     unsigned long long nhits;
     unsigned long long trace_counters[4];
 };
@@ -397,7 +397,7 @@ vx_status extent_from_bbox(const float* bb, size_t nv, float vs, Extent* e)
 vx_status compute_extent(const vx_mesh* m, float vs, Small* dsmall, Mail* mail, hipStream_t s, Extent* e)
 {
     // one kernel: reduction, result into the host mailbox, state restored, per-build setVoxel counter cleared
-    vx::launch_bbox(m->dv, m->nv, dsmall->bbox_state, mail->bbox, &dsmall->set_calls, s);
+    vx::launch_bbox(m->dv, m->nv, dsmall->bbox_state, mail->bbox, dsmall->set_calls, s);
     VX_HIP(hipStreamSynchronize(s));
     return extent_from_bbox(mail->bbox, m->nv, vs, e);
 }
@@ -507,9 +507,11 @@ vx_status sync_counts(vx_grid* g)
 {
     if (g->counts_valid) return VX_OK;
     DeviceGuard dg(g->device);
-    unsigned long long sc = 0;
-    VX_HIP(hipMemcpyAsync(&sc, &g->small.as<Small>()->set_calls, 8, hipMemcpyDeviceToHost, g->stream));
+    unsigned long long part[vx::kCallCounters * 8];
+    VX_HIP(hipMemcpyAsync(part, g->small.as<Small>()->set_calls, sizeof(part), hipMemcpyDeviceToHost, g->stream));
     VX_HIP(hipStreamSynchronize(g->stream));
+    unsigned long long sc = 0;
+    for (uint32_t i = 0; i < vx::kCallCounters; ++i) sc += part[8 * i];
     g->set_calls = sc + g->host_set_calls;
     g->counts_valid = true;
     return VX_OK;
@@ -523,7 +525,7 @@ vx_status init_grid_storage(vx_grid* g, bool clear = true)
     VX_HIP(g->words.ensure((size_t)(g->g.nwords + 2) * 4));
     if (clear) {
         VX_HIP(hipMemsetAsync(g->words.p, 0, (size_t)(g->g.nwords + 2) * 4, g->stream));
-        VX_HIP(hipMemsetAsync(&g->small.as<Small>()->set_calls, 0, 8, g->stream));
+        VX_HIP(hipMemsetAsync(g->small.as<Small>()->set_calls, 0, sizeof(Small::set_calls), g->stream));
     }
     g->coarse_valid = g->prefix_valid = g->occupied_known = false;
     g->counts_valid = true;
@@ -724,7 +726,7 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
         const float zero3[3] = {0.f, 0.f, 0.f};
         const uint64_t zdim[3] = {0, 0, 0};
         fill_params(gp, zero3, vs, zdim);
-        vx::launch_bbox(mesh->dv, mesh->nv, ds->bbox_state, g->mail->bbox, &ds->set_calls, s, vs, &ds->dgrid);
+        vx::launch_bbox(mesh->dv, mesh->nv, ds->bbox_state, g->mail->bbox, ds->set_calls, s, vs, &ds->dgrid);
         VX_TRY(setup_launch(mesh, gp, o.sat_variant, tb, ntri, 0, 0, g->recs, g->units, g->ubase, g->scantmp, g->mail, s, &ds->dgrid));
         if (g->words.p) {
             VX_HIP(hipMemsetAsync(g->words.p, 0, g->words.cap, s));
@@ -781,7 +783,7 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
         umask = g->umask.as<uint32_t>();
     }
     vx::launch_voxelize(g->recs.as<vx::TriRec>(), g->ubase.as<uint32_t>(), g->btri.as<uint32_t>(), ntri, g->g, o.sat_variant,
-                        g->words.as<uint32_t>(), wb, we, umask, &ds->set_calls, s);
+                        g->words.as<uint32_t>(), wb, we, umask, ds->set_calls, s);
     g->counts_valid = false;
     if (g->kind == VX_GRID_VEC) {
         // VoxelGridVec::setVoxel appends one Aabb per call (voxelgridVecEncoding.cpp:19-39): ordered emission
@@ -1461,7 +1463,7 @@ vx_status vx_octree_build(const vx_mesh* mesh_c, float vs, uint64_t max_items, v
         OCT_HIP(umask.ensure((size_t)(U + 1) * 4));
         OCT_HIP(hbase.ensure((size_t)(U + 2) * 4));
         OCT_HIP(ensure_scan_tmp(scantmp, vx::scan_tmp_bytes(U), s));
-        vx::launch_voxelize(recs.as<vx::TriRec>(), ubase.as<uint32_t>(), btri.as<uint32_t>(), ntri, g, 0, nullptr, 0, 0, umask.as<uint32_t>(), &ds->set_calls, s);
+        vx::launch_voxelize(recs.as<vx::TriRec>(), ubase.as<uint32_t>(), btri.as<uint32_t>(), ntri, g, 0, nullptr, 0, 0, umask.as<uint32_t>(), ds->set_calls, s);
         vx::launch_scan_u32(umask.as<uint32_t>(), hbase.as<uint32_t>(), U, true, scantmp.p, &mail->hits, s, true);
         OCT_HIP(hipStreamSynchronize(s));
         hits = mail->hits;

@@ -42,7 +42,8 @@ struct ProfScope {
 // ---- launchers (all asynchronous on `s`) ------------------------------------------------------------------
 // K1: bbox of all vertices with the reference's first-occurrence tie rule; out6 = min xyz, max xyz (device).
 // state7: self-cleaning reduction state (initialise ONCE with bbox_state_init); out6 may point to pinned host memory;
-// zero64 (optional) is cleared by the kernel.
+// zero64 (optional): the per-build setVoxel-call counters (kCallCounters of them, one per 64-byte line), cleared by the kernel.
+constexpr uint32_t kCallCounters = 64;  // k_voxelize's waves add to counter (wave index % 64): entry [8 * i] of the array
 // dgrid (optional, device memory): origin = bbox min and dims = ceil((max - min) / vs) as the host will derive them, for kernels
 // queued behind K1 before the host has read the bbox.
 struct DevGrid {

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void k_bbox(const float* __restrict__ verts, u
         __hip_atomic_store(&state[a], a < 3 ? ~0ull : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (threadIdx.x == 6) __hip_atomic_store(&state[6], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (threadIdx.x == 7 && zero64) *zero64 = 0ull;
+    if (zero64 && threadIdx.x >= 64u && threadIdx.x < 64u + kCallCounters) zero64[(threadIdx.x - 64u) * 8u] = 0ull;
     if (dgrid && threadIdx.x < 64) {
         // the grid the host will derive from this bbox (VoxelBuilder.hpp:347-349: origin = bbox min, dim = ceil((max - min) / vs),
         // same IEEE division), for the kernels that are queued before the host has seen the bbox
@@ -603,8 +603,10 @@ void launch_unit_blocks(const uint32_t* unit_base, uint32_t ntri, uint32_t total
 // [0] issue of the next pass's staging, [1] unit search + record read, [2] the functor (SAT / emission), [3] rest
 __device__ unsigned long long g_vox_dbg[8];
 #define VX_V_T(i) { const unsigned long long now_ = __builtin_readcyclecounter(); vdbg[i] += now_ - vlast; vlast = now_; }
+#define VX_V_SENT ++sent;
 #else
 #define VX_V_T(i)
+#define VX_V_SENT
 #endif
 
 struct __attribute__((aligned(16))) UnitStage {  // one wave's staging buffer
@@ -715,7 +717,7 @@ __device__ __forceinline__ void for_each_unit(const TriRec* __restrict__ recs, c
         cur ^= 1;
     }
 #ifdef VX_VOX_DEBUG
-    if (lane == 0) for (int i = 0; i < 6; ++i) atomicAdd(&g_vox_dbg[i], vdbg[i]);
+    if (lane == 0) for (int i = 0; i < 5; ++i) atomicAdd(&g_vox_dbg[i], vdbg[i]);  // ([5]: requests sent, [6], [7]: k_voxelize)
 #endif
 }
 
@@ -731,6 +733,9 @@ __global__ __launch_bounds__(256) void k_voxelize(const TriRec* __restrict__ rec
 {
     __shared__ UnitStage stage[kStagesPerBlock];
     unsigned hits = 0;
+#ifdef VX_VOX_DEBUG
+    unsigned sent = 0;  // atomic requests this lane really sent
+#endif
     for_each_unit(recs, unit_base, block_tri, ntri, stage, [&](uint32_t u, uint32_t t, const TriRec& r, uint32_t rel) {
         const Unit w = decode_unit(r, t, rel);
         const float cy = cell_centre(g.org[1], g.vs, w.y), cz = cell_centre(g.org[2], g.vs, w.z);
@@ -789,14 +794,20 @@ __global__ __launch_bounds__(256) void k_voxelize(const TriRec* __restrict__ rec
             // memory side and drop the line from L2 instead of updating it, nothing else writes the mask in this kernel, and
             // what older kernels left in the caches (the previous build's mask) is invalidated at the kernel boundary like every
             // other buffer this pipeline passes from kernel to kernel.  A stale copy can only show fewer bits: one request more.
-            if (lo && wi >= wb && wi < we) { if ((words[wi] & lo) != lo) atomicOr(&words[wi], lo); hits += __popc(lo); }        // voxelgridBool.cpp:66
-            if (hi && wi + 1 >= wb && wi + 1 < we) { if ((words[wi + 1] & hi) != hi) atomicOr(&words[wi + 1], hi); hits += __popc(hi); }
+            if (lo && wi >= wb && wi < we) { if ((words[wi] & lo) != lo) { atomicOr(&words[wi], lo); VX_V_SENT } hits += __popc(lo); }        // voxelgridBool.cpp:66
+            if (hi && wi + 1 >= wb && wi + 1 < we) { if ((words[wi + 1] & hi) != hi) { atomicOr(&words[wi + 1], hi); VX_V_SENT } hits += __popc(hi); }
 #endif
         }
     });
     hits = wave_sum_u32(hits);
+#ifdef VX_VOX_DEBUG
+    sent = wave_sum_u32(sent);
+    if ((threadIdx.x & 63) == 0 && sent) atomicAdd(&g_vox_dbg[5], (unsigned long long)sent);
+#endif
 #ifndef VX_DIAG_NO_SETCALLS
-    if ((threadIdx.x & 63) == 0 && hits) atomicAdd(set_calls, (unsigned long long)hits);
+    // 64 counters on 64-byte lines of their own, a wave adds to one of them: thousands of adds on ONE address queue at the memory-side
+    // atomic unit at ~12 ns each -- 8192 waves: 100 us, which was this kernel's tail once the bitmask requests got fewer
+    if ((threadIdx.x & 63) == 0 && hits) atomicAdd(set_calls + ((blockIdx.x * 4u + (threadIdx.x >> 6)) & (kCallCounters - 1u)) * 8u, (unsigned long long)hits);
 #endif
 }
 
