@@ -281,6 +281,7 @@ struct vx_grid {
     bool coarse_valid = false, prefix_valid = false /*word_prefix queued or done*/, occupied_known = false, counts_valid = true;
     uint64_t occupied = 0, set_calls = 0, host_set_calls = 0;
     uint64_t vec_count = 0;
+    int trace_phase = 0;  // which of Small::trace_counters[0..1] the next ray launch draws its work from (the launch clears the other)
     // VX_GRID_VEC: the caller's own list buffer (vx_grid_bind_aabbs_device); builds emit straight into it when it is large enough
     vx_aabb* bound = nullptr;
     uint64_t bound_cap = 0;
@@ -1286,7 +1287,7 @@ static vx_status trace_common(vx_grid* g, vx::TraceIO io)
         VX_HIP(hipStreamSynchronize(g->stream));  // the host copy lives on the caller's stack
         io.cam_dev = g->camera.as<vx::Camera>();
     }
-    vx::launch_trace(g->g, mips, prefix, io, g->small.as<Small>()->trace_counters, idx_tmp, g->stream);
+    vx::launch_trace(g->g, mips, prefix, io, g->small.as<Small>()->trace_counters, &g->trace_phase, idx_tmp, g->stream);
     VX_HIP(hipGetLastError());
     return VX_OK;
 }

@@ -128,7 +128,7 @@ struct TraceIO {
 // voxel indices of the hits travel from the walk to the rank pass as 32-bit words when they fit (all ones = miss)
 inline bool trace_idx32(const GridParams& g) { return g.nvox < 0xFFFFFFFFull; }
 inline size_t trace_idx_bytes(const GridParams& g, uint64_t nrays) { return (size_t)nrays * (trace_idx32(g) ? 4 : 8) + 8; }
-void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* word_prefix, const TraceIO& io, unsigned long long* counters /*1 device word*/,
+void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* word_prefix, const TraceIO& io, unsigned long long* counters /*2 device words, zero before the first trace; they alternate*/, int* phase /*host*/,
                   void* idx_tmp /*trace_idx_bytes when ranks / normals / the hit list are wanted*/, hipStream_t s);
 
 // single-voxel helpers

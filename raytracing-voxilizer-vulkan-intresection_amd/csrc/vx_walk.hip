@@ -372,6 +372,7 @@ struct WalkCold {
     void* idx_out;                // IdxT per ray: voxel index of the hit, all ones = miss
     uint8_t* shadowed_out;
     unsigned long long* next_item;   // work counter
+    unsigned long long* next_zero;   // the NEXT launch's work counter: cleared by this launch (two counters alternate: no memset between traces)
 };
 struct WalkParams {
     WalkHot hot;
@@ -743,6 +744,7 @@ __global__ __launch_bounds__(VX_W_BLOCK, VX_W_MINWAVES) void k_walk(const WalkPa
     constexpr uint32_t kWavesPerBlock = VX_W_BLOCK / 64;
     const GridParams& g = P.g;
     extern __shared__ __attribute__((aligned(16))) uint32_t mips_lds[];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *walk_cold()->next_zero = 0ull;
     if (LDS_MIPS) {
         for (uint32_t i = threadIdx.x; i < P.m1_words; i += VX_W_BLOCK) mips_lds[i] = P.w1[i];
         for (uint32_t i = threadIdx.x; i < P.m2_words; i += VX_W_BLOCK) mips_lds[P.m1_words + i] = P.w2[i];
@@ -1029,7 +1031,8 @@ extern "C" int vx_debug_walk_ts(unsigned long long* out /*[3 * 8192]*/)
 namespace vx {
 #endif
 
-void launch_walk(const GridParams& g, const TraceMips& mips, const TraceIO& io, unsigned long long* counter, void* idx_out, bool idx32, hipStream_t s)
+void launch_walk(const GridParams& g, const TraceMips& mips, const TraceIO& io, unsigned long long* counters /*[2], both zero before the first launch*/,
+                 int* phase /*host: which of the two the next launch draws from*/, void* idx_out, bool idx32, hipStream_t s)
 {
     if (!io.nrays) return;
     const uint64_t n1 = (uint64_t)mips.d1[0] * mips.d1[1] * mips.d1[2], n2 = (uint64_t)mips.d2[0] * mips.d2[1] * mips.d2[2];
@@ -1059,14 +1062,16 @@ void launch_walk(const GridParams& g, const TraceMips& mips, const TraceIO& io, 
     P.cold.t_out = io.t_out;
     P.cold.idx_out = idx_out;
     P.cold.shadowed_out = io.shadowed_out;
-    P.cold.next_item = counter;
+
     const size_t shmem = lds ? (size_t)(m1_words + m2_words) * 4 : 0;
     // one launch per 2^31 rays: ray indices inside the kernel are 32-bit
     for (uint64_t base = 0; base < io.nrays; base += 0x80000000ull) {
         const uint64_t n = io.nrays - base < 0x80000000ull ? io.nrays - base : 0x80000000ull;
         P.hot.nrays = (uint32_t)n;
         P.cold.ray_base = base;
-        (void)hipMemsetAsync(counter, 0, sizeof(unsigned long long), s);
+        P.cold.next_item = counters + (*phase & 1);
+        P.cold.next_zero = counters + ((*phase & 1) ^ 1);
+        *phase ^= 1;
         uint64_t max_blocks = 256ull * VX_W_MINWAVES * 4ull * 64ull / VX_W_BLOCK;  // one resident set of waves
         // Batches of a few rays per lane: the launch ends with every wave draining the rays it started last, a span of about two mean
         // ray latencies whatever the batch; with somewhat fewer waves a lane sees at least ~4 rays and the same work drains from fewer
