@@ -495,7 +495,7 @@ vx_status ensure_coarse(vx_grid* g)
     VX_HIP(g->c2words.ensure((size_t)((nc2 + 31) / 32 + 2) * 4));
     VX_HIP(g->bricks.ensure((size_t)(nc * 8 * 3 + 8) * 8));  // three orientations (x, y, z slabs)
     // bitmask -> brick-major slabs in three orientations -> level-1 mip (from the z orientation) -> level-2 mip
-    static const bool fuse_mip1 = !(getenv("VOXHIP_FUSE_MIP1") && atoi(getenv("VOXHIP_FUSE_MIP1")) == 0);  // 0: the separate kernel, every brick stored (tests)
+    const bool fuse_mip1 = !(getenv("VOXHIP_FUSE_MIP1") && atoi(getenv("VOXHIP_FUSE_MIP1")) == 0);  // 0: the separate kernel, every brick stored (tests)
     const bool fused = vx::launch_build_bricks3(g->words.as<uint32_t>(), g->g.dim, g->cdim, g->bricks.as<unsigned long long>(),
                                                 fuse_mip1 ? g->cwords.as<uint32_t>() : nullptr, g->stream);
     if (!fused) vx::launch_brick_mip1(g->bricks.as<unsigned long long>() + 2ull * nc * 8ull, nc, g->cwords.as<uint32_t>(), g->stream);

@@ -130,6 +130,31 @@ def test_trace_forced_paths(gpu, name, vs, lds, donate):
         assert np.array_equal(tt, ot)
 
 
+def test_brick_kernel_fused_and_separate_mip(gpu):
+    """A grid whose brick rows are multiples of 64 (512^3): the brick kernel writes the level-1 mip itself and leaves empty bricks
+    unwritten -- also on top of the stale bricks of an earlier, different build in the same handle; VOXHIP_FUSE_MIP1=0 stores every
+    brick and derives the mip separately.  Same rays, same answers (the fused path itself is checked against the oracle by C3)."""
+    v, t = vx_scenes.scene("soup2000")
+    ext = float((v.max(0) - v.min(0)).max())
+    vs = np.float32(ext / 512)
+    mesh = gpu.Mesh.from_arrays(v, t)
+    rays = np.concatenate([vx_scenes.random_rays(20000, v.min(0), v.max(0), seed=5), vx_scenes.random_rays(20000, v.min(0) - 1, v.max(0) + 1, seed=6)])
+    with env(VOXHIP_FUSE_MIP1=0):
+        g0 = gpu.Grid.voxelize(mesh, vs)
+        t0, p0, _ = g0.trace(rays)
+    # the fused build runs in a handle that first held ANOTHER mesh at the same resolution: bricks of that build that are empty
+    # now keep their old words and must never be looked at
+    v2 = (v + np.float32(0.013) * ext).astype(np.float32)
+    v2 = np.minimum(np.maximum(v2, v.min(0)), v.max(0)).astype(np.float32)
+    v2[0], v2[1] = v.min(0), v.max(0)          # same bounding box, hence the same grid
+    g1 = gpu.Grid.voxelize(gpu.Mesh.from_arrays(v2, t), vs)
+    g1.trace(rays[:1000])
+    g1.revoxelize(mesh, vs)
+    assert g1.describe()["dim"] == g0.describe()["dim"] and np.array_equal(g1.bitmask(), g0.bitmask())
+    t1, p1, _ = g1.trace(rays)
+    assert np.array_equal(t0, t1) and np.array_equal(p0, p1) and (t1 > 0).sum() > 1000
+
+
 # ---------------------------------------------------------------------------------------------- exact-zero direction components
 @pytest.mark.parametrize("name,vs", [("cube", 0.0625), ("rotcube", 0.031), ("adversarial", 0.0625), ("blob70k", 2.0 / 128), ("soup2000", 1.0 / 256)])
 def test_trace_zero_direction_components(gpu, name, vs):
