@@ -3,6 +3,7 @@
 #include "vx_internal.h"
 
 #include <cmath>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -184,6 +185,19 @@ struct Mail {
     unsigned long long units, hits, occupied, pad;
 };
 
+// Totals may arrive tagged with the build's sequence number in bits 48..63 (see launch_scan_u32): the host then polls the word
+// instead of draining the stream -- the totals are written by scans that finish long before the build's last kernel.
+constexpr unsigned long long kMailValue = (1ull << 48) - 1ull;
+inline bool mail_wait(const volatile unsigned long long* a, const volatile unsigned long long* b /*optional*/, unsigned long long tag, double timeout_ms)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0;; ++spin) {
+        if ((*a & ~kMailValue) == tag && (!b || (*b & ~kMailValue) == tag)) return true;
+        if ((spin & 255u) == 255u && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > timeout_ms) return false;
+        __builtin_ia32_pause();
+    }
+}
+
 hipError_t mail_alloc(Mail** out)
 {
     void* p = nullptr;
@@ -281,6 +295,7 @@ struct vx_grid {
     bool coarse_valid = false, prefix_valid = false /*word_prefix queued or done*/, occupied_known = false, counts_valid = true;
     uint64_t occupied = 0, set_calls = 0, host_set_calls = 0;
     uint64_t vec_count = 0;
+    uint32_t mail_seq = 0;  // sequence tag of the totals the current build writes to the mailbox
     int trace_phase = 0;  // which of Small::trace_counters[0..1] the next ray launch draws its work from (the launch clears the other)
     // VX_GRID_VEC: the caller's own list buffer (vx_grid_bind_aabbs_device); builds emit straight into it when it is large enough
     vx_aabb* bound = nullptr;
@@ -437,7 +452,7 @@ vx_status setup_launch(const vx_mesh* m, const vx::GridParams& g, int sat, uint6
 vx_status setup_finish(uint32_t ntri, DevBuf& ubase, DevBuf& btri, Mail* mail, hipStream_t s, uint64_t* total_units, bool stream_is_drained = false)
 {
     if (!stream_is_drained) VX_HIP(hipStreamSynchronize(s));
-    const unsigned long long tot = mail->units;
+    const unsigned long long tot = mail->units & kMailValue;
     if (tot >= 0xFFFFFFFFull) return fail(VX_ERR_CAPACITY, "more than 2^32 candidate row segments: shard the mesh or the grid");
     *total_units = tot;
     if (tot) {
@@ -449,13 +464,15 @@ vx_status setup_finish(uint32_t ntri, DevBuf& ubase, DevBuf& btri, Mail* mail, h
 
 // word_prefix + occupied count.  Split in two so that callers can queue dependent kernels before the host waits for the
 // count (a host sync in front of a kernel leaves the GPU idle and the clocks down for its start).
-vx_status prefix_launch(vx_grid* g, bool* pending)
+vx_status prefix_launch(vx_grid* g, bool* pending, unsigned long long tag = 0, bool* tagged = nullptr)
 {
     *pending = !g->occupied_known;
+    if (tagged) *tagged = false;
     if (g->prefix_valid) return VX_OK;
     VX_HIP(g->wprefix.ensure((size_t)(g->g.nwords + 2) * 4));
     VX_HIP(ensure_scan_tmp(g->scantmp, vx::scan_tmp_bytes(g->g.nwords), g->stream));
-    vx::launch_scan_u32(g->words.as<uint32_t>(), g->wprefix.as<uint32_t>(), g->g.nwords, true, g->scantmp.p, &g->mail->occupied, g->stream, true);
+    const bool tg = vx::launch_scan_u32(g->words.as<uint32_t>(), g->wprefix.as<uint32_t>(), g->g.nwords, true, g->scantmp.p, &g->mail->occupied, g->stream, true, tag);
+    if (tagged) *tagged = tg && tag != 0;
     g->prefix_valid = true;
     g->occupied_known = false;
     *pending = true;
@@ -466,7 +483,7 @@ vx_status prefix_finish(vx_grid* g, bool pending)
 {
     if (!pending || g->occupied_known) return VX_OK;
     VX_HIP(hipStreamSynchronize(g->stream));
-    const unsigned long long tot = g->mail->occupied;
+    const unsigned long long tot = g->mail->occupied & kMailValue;
     if (tot >= 0xFFFFFFFFull) return fail(VX_ERR_CAPACITY, "more than 2^32 occupied voxels");
     g->occupied = tot;
     g->occupied_known = true;
@@ -786,11 +803,15 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
     vx::launch_voxelize(g->recs.as<vx::TriRec>(), g->ubase.as<uint32_t>(), g->btri.as<uint32_t>(), ntri, g->g, o.sat_variant,
                         g->words.as<uint32_t>(), wb, we, umask, ds->set_calls, s);
     g->counts_valid = false;
+    // sequence tag of this build's totals in the mailbox (never 0: an untagged word never matches)
+    g->mail_seq = (g->mail_seq % 0xFFFFu) + 1u;
+    const unsigned long long mtag = (unsigned long long)g->mail_seq << 48;
+    bool hits_tagged = false, occ_tagged = false, occ_queued = false;
     if (g->kind == VX_GRID_VEC) {
         // VoxelGridVec::setVoxel appends one Aabb per call (voxelgridVecEncoding.cpp:19-39): ordered emission
         VX_HIP(g->hbase.ensure((size_t)(U + 2) * 4));
         VX_HIP(ensure_scan_tmp(g->scantmp, vx::scan_tmp_bytes(U), s));
-        vx::launch_scan_u32(umask, g->hbase.as<uint32_t>(), U, true, g->scantmp.p, &g->mail->hits, s, true);
+        hits_tagged = vx::launch_scan_u32(umask, g->hbase.as<uint32_t>(), U, true, g->scantmp.p, &g->mail->hits, s, true, mtag);
     }
     // A complete (unsharded) bitmask: queue what every consumer of the grid needs next -- the traversal structure (bricks,
     // bounds, mips = the reference's acceleration-structure build, hello_vulkan.cpp:700-703) and the word prefix (getAabbs /
@@ -800,7 +821,8 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
     if (eager && wb == 0 && we == g->g.nwords) {
         VX_TRY(ensure_coarse(g));
         bool pending = false;
-        VX_TRY(prefix_launch(g, &pending));
+        occ_queued = !g->prefix_valid;
+        VX_TRY(prefix_launch(g, &pending, mtag, &occ_tagged));
     }
     if (g->kind == VX_GRID_VEC) {
         // The list is emitted into the handle's existing buffer before the host knows the hit count (writes beyond the
@@ -812,12 +834,21 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
         if (cap_rec)
             vx::launch_emit_units(g->recs.as<vx::TriRec>(), g->ubase.as<uint32_t>(), g->btri.as<uint32_t>(), ntri, g->g, umask,
                                   g->hbase.as<uint32_t>(), tgt, nullptr, s, to_bound ? g->bound_cap : cap_rec);
-        VX_HIP(hipStreamSynchronize(s));
-        const unsigned long long hits = g->mail->hits;
+        // The host needs the hit count (and takes the occupied count along).  Both are written by scans that run BEFORE the
+        // emission: the host polls the tagged mailbox words and goes on queueing work (the caller's next call: a trace) while
+        // the emission still runs; a stream synchronize would wake it ~15 us after the last kernel.  VOXHIP_POLL_MAIL=0, an
+        // untagged total (three-pass scan) or 5 ms without an answer: the synchronize.
+        static const bool poll = !(getenv("VOXHIP_POLL_MAIL") && atoi(getenv("VOXHIP_POLL_MAIL")) == 0);
+        const bool occ_in_flight = g->prefix_valid && !g->occupied_known;
+        bool got = false;
+        if (poll && hits_tagged && (!occ_in_flight || (occ_queued && occ_tagged)))
+            got = mail_wait(&g->mail->hits, occ_in_flight ? &g->mail->occupied : nullptr, mtag, 5.0);
+        if (!got) VX_HIP(hipStreamSynchronize(s));
+        const unsigned long long hits = g->mail->hits & kMailValue;
         if (hits >= 0xFFFFFFFFull) return fail(VX_ERR_CAPACITY, "more than 2^32 voxel hits");
         if (g->prefix_valid) {  // the same wait covered the occupied count
-            if (g->mail->occupied >= 0xFFFFFFFFull) return fail(VX_ERR_CAPACITY, "more than 2^32 occupied voxels");
-            g->occupied = g->mail->occupied;
+            if ((g->mail->occupied & kMailValue) >= 0xFFFFFFFFull) return fail(VX_ERR_CAPACITY, "more than 2^32 occupied voxels");
+            g->occupied = g->mail->occupied & kMailValue;
             g->occupied_known = true;
         }
         if (hits + 1 <= cap_rec) g->vec_in_bound = to_bound;
@@ -1467,7 +1498,7 @@ vx_status vx_octree_build(const vx_mesh* mesh_c, float vs, uint64_t max_items, v
         vx::launch_voxelize(recs.as<vx::TriRec>(), ubase.as<uint32_t>(), btri.as<uint32_t>(), ntri, g, 0, nullptr, 0, 0, umask.as<uint32_t>(), ds->set_calls, s);
         vx::launch_scan_u32(umask.as<uint32_t>(), hbase.as<uint32_t>(), U, true, scantmp.p, &mail->hits, s, true);
         OCT_HIP(hipStreamSynchronize(s));
-        hits = mail->hits;
+        hits = mail->hits & kMailValue;
         if (hits >= 0xFFFFFFFFull) return bail(fail(VX_ERR_CAPACITY, "more than 2^32 octree items"));
     }
     o->nitems = hits;

@@ -62,8 +62,10 @@ void launch_tri_setup(const float* verts, const int32_t* idx, uint64_t tri_begin
 // exclusive scan of n uint32 (or of their popcounts) into out[0..n] (out[n] = total, saturating check via *total64)
 size_t scan_tmp_bytes(uint64_t n);
 // tmp_is_zero: the caller guarantees tmp (scan_tmp_bytes(n)) is all zero; the scan leaves it all zero again.
-void launch_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, bool popcount_input, void* tmp,
-                     unsigned long long* total64, hipStream_t s, bool tmp_is_zero = false);
+// total_tag (bits 48..63 only): OR-ed into *total64 by the single-pass kernel, so that a host polling a pinned mailbox word can tell
+// this scan's total from an older one; returns whether the tag was applied (false: the three-pass path, *total64 is the bare total).
+bool launch_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, bool popcount_input, void* tmp,
+                     unsigned long long* total64, hipStream_t s, bool tmp_is_zero = false, unsigned long long total_tag = 0);
 
 // K2: triangle/voxel overlap over all work units; ORs hits into `words` (only words in [wb,we)), optionally
 // stores each unit's 32-bit hit mask (unit_mask) for the ordered emitters; adds the hit count to *set_calls.

@@ -297,7 +297,7 @@ constexpr int kOneBlock = VX_SCAN_BLOCK, kOneItems = VX_SCAN_ITEMS, kOneTile = k
 template <bool POPC>
 __global__ __launch_bounds__(kOneBlock) void k_scan_onepass(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t n,
                                                            unsigned long long* status /*[0]: ticket, [1]: finished tiles, [2 + tile]: state*/, uint32_t ntiles,
-                                                           unsigned long long* total)
+                                                           unsigned long long* total, unsigned long long total_tag /*OR-ed into *total: bits 48..63*/)
 {
     __shared__ unsigned wsum[kOneBlock / 64];
     __shared__ unsigned tile_s;
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(kOneBlock) void k_scan_onepass(const uint32_t* __re
         }
         if (lane == 0) {
             prefix_s = excl;
-            if (tile == ntiles - 1 && total) *total = excl + (unsigned long long)btot;
+            if (tile == ntiles - 1 && total) *total = total_tag | (excl + (unsigned long long)btot);
         }
     }
     __syncthreads();
@@ -401,8 +401,8 @@ __global__ __launch_bounds__(kOneBlock) void k_scan_onepass(const uint32_t* __re
 
 size_t scan_tmp_bytes(uint64_t n) { return (size_t)(((n + 1) + kScanTile - 1) / kScanTile + 4) * sizeof(unsigned long long); }
 
-void launch_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, bool popcount_input, void* tmp, unsigned long long* total64,
-                     hipStream_t s, bool tmp_is_zero)
+bool launch_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, bool popcount_input, void* tmp, unsigned long long* total64,
+                     hipStream_t s, bool tmp_is_zero, unsigned long long total_tag)
 {
     const uint32_t nblocks = (uint32_t)(((n + 1) + kScanTile - 1) / kScanTile);
     unsigned long long* status = (unsigned long long*)tmp;
@@ -411,9 +411,9 @@ void launch_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, bool popcoun
     if (!three_pass && aligned) {
         const uint32_t ntiles = (uint32_t)(((n + 1) + kOneTile - 1) / kOneTile);
         if (!tmp_is_zero) (void)hipMemsetAsync(status, 0, (size_t)(ntiles + 2) * sizeof(unsigned long long), s);
-        if (popcount_input) VX_KL(k_scan_onepass<true>, dim3(ntiles), dim3(kOneBlock), 0, s, in, out, n, status, ntiles, total64);
-        else VX_KL(k_scan_onepass<false>, dim3(ntiles), dim3(kOneBlock), 0, s, in, out, n, status, ntiles, total64);
-        return;
+        if (popcount_input) VX_KL(k_scan_onepass<true>, dim3(ntiles), dim3(kOneBlock), 0, s, in, out, n, status, ntiles, total64, total_tag);
+        else VX_KL(k_scan_onepass<false>, dim3(ntiles), dim3(kOneBlock), 0, s, in, out, n, status, ntiles, total64, total_tag);
+        return true;
     }
     unsigned long long* sums = status;
     if (popcount_input) {
@@ -426,6 +426,7 @@ void launch_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, bool popcoun
         VX_KL(k_scan_apply<false>, dim3(nblocks), dim3(kScanBlock), 0, s, in, out, n, sums);
     }
     if (tmp_is_zero) (void)hipMemsetAsync(status, 0, scan_tmp_bytes(n), s);  // keep the caller's "zero between scans" contract
+    return false;  // (*total64 carries no tag)
 }
 
 // ------------------------------------------------------------------------------------------------------------
