@@ -438,14 +438,16 @@ constexpr uint64_t kMaxVoxels = 1ull << 37;  // 16 GiB of bitmask
 // The shared front half of buildVoxelGrid for grids and the octree: records, unit counts, unit bases.  In two parts so that
 // the caller can queue work that does not depend on the unit count (clearing the bitmask) before the host waits for it.
 vx_status setup_launch(const vx_mesh* m, const vx::GridParams& g, int sat, uint64_t tb, uint32_t ntri, uint32_t zlo, uint32_t zhi, DevBuf& recs,
-                       DevBuf& units, DevBuf& ubase, DevBuf& scantmp, Mail* mail, hipStream_t s, const vx::DevGrid* dgrid = nullptr)
+                       DevBuf& units, DevBuf& ubase, DevBuf& scantmp, Mail* mail, hipStream_t s, const vx::DevGrid* dgrid = nullptr,
+                       unsigned long long mail_tag = 0, bool* tagged = nullptr)
 {
     VX_HIP(recs.ensure((size_t)ntri * sizeof(vx::TriRec) + 64));
     VX_HIP(units.ensure(((size_t)ntri + 1) * 4));
     VX_HIP(ubase.ensure(((size_t)ntri + 2) * 4));
     VX_HIP(ensure_scan_tmp(scantmp, vx::scan_tmp_bytes(ntri), s));
     vx::launch_tri_setup(m->dv, m->di, tb, ntri, g, sat, zlo, zhi, recs.as<vx::TriRec>(), units.as<uint32_t>(), s, dgrid);
-    vx::launch_scan_u32(units.as<uint32_t>(), ubase.as<uint32_t>(), ntri, false, scantmp.p, &mail->units, s, true);
+    const bool tg = vx::launch_scan_u32(units.as<uint32_t>(), ubase.as<uint32_t>(), ntri, false, scantmp.p, &mail->units, s, true, mail_tag);
+    if (tagged) *tagged = tg && mail_tag != 0;
     return VX_OK;
 }
 
@@ -736,6 +738,11 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
     // Unsharded build: K1 leaves origin + dims in device memory, so the triangle records and the unit scan are queued right
     // behind it and the host waits ONCE for the bbox and the unit count (every host round trip costs ~20 us of idle GPU: the
     // wake-up plus the launch latency of an empty queue).  The bitmask of the previous build is cleared in the same window.
+    // sequence tag of this build's totals in the mailbox (never 0: an untagged word never matches); VOXHIP_POLL_MAIL=0: the host
+    // drains the stream instead of polling the mailbox
+    g->mail_seq = (g->mail_seq % 0xFFFFu) + 1u;
+    const unsigned long long mtag = (unsigned long long)g->mail_seq << 48;
+    static const bool poll_mail = !(getenv("VOXHIP_POLL_MAIL") && atoi(getenv("VOXHIP_POLL_MAIL")) == 0);
     Extent ex;
     bool setup_queued = false;
     size_t cleared = 0;
@@ -745,12 +752,14 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
         const uint64_t zdim[3] = {0, 0, 0};
         fill_params(gp, zero3, vs, zdim);
         vx::launch_bbox(mesh->dv, mesh->nv, ds->bbox_state, g->mail->bbox, ds->set_calls, s, vs, &ds->dgrid);
-        VX_TRY(setup_launch(mesh, gp, o.sat_variant, tb, ntri, 0, 0, g->recs, g->units, g->ubase, g->scantmp, g->mail, s, &ds->dgrid));
+        bool units_tagged = false;
+        VX_TRY(setup_launch(mesh, gp, o.sat_variant, tb, ntri, 0, 0, g->recs, g->units, g->ubase, g->scantmp, g->mail, s, &ds->dgrid, mtag, &units_tagged));
         if (g->words.p) {
             VX_HIP(hipMemsetAsync(g->words.p, 0, g->words.cap, s));
             cleared = g->words.cap;
         }
-        VX_HIP(hipStreamSynchronize(s));
+        // the bbox (written by k_bbox, two kernels earlier) and the unit total: polled from the mailbox, see the hit count below
+        if (!(poll_mail && units_tagged && mail_wait(&g->mail->units, nullptr, mtag, 5.0))) VX_HIP(hipStreamSynchronize(s));
         VX_TRY(extent_from_bbox(g->mail->bbox, mesh->nv, vs, &ex));
         setup_queued = true;
     } else {
@@ -803,9 +812,6 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
     vx::launch_voxelize(g->recs.as<vx::TriRec>(), g->ubase.as<uint32_t>(), g->btri.as<uint32_t>(), ntri, g->g, o.sat_variant,
                         g->words.as<uint32_t>(), wb, we, umask, ds->set_calls, s);
     g->counts_valid = false;
-    // sequence tag of this build's totals in the mailbox (never 0: an untagged word never matches)
-    g->mail_seq = (g->mail_seq % 0xFFFFu) + 1u;
-    const unsigned long long mtag = (unsigned long long)g->mail_seq << 48;
     bool hits_tagged = false, occ_tagged = false, occ_queued = false;
     if (g->kind == VX_GRID_VEC) {
         // VoxelGridVec::setVoxel appends one Aabb per call (voxelgridVecEncoding.cpp:19-39): ordered emission
@@ -838,10 +844,9 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
         // emission: the host polls the tagged mailbox words and goes on queueing work (the caller's next call: a trace) while
         // the emission still runs; a stream synchronize would wake it ~15 us after the last kernel.  VOXHIP_POLL_MAIL=0, an
         // untagged total (three-pass scan) or 5 ms without an answer: the synchronize.
-        static const bool poll = !(getenv("VOXHIP_POLL_MAIL") && atoi(getenv("VOXHIP_POLL_MAIL")) == 0);
         const bool occ_in_flight = g->prefix_valid && !g->occupied_known;
         bool got = false;
-        if (poll && hits_tagged && (!occ_in_flight || (occ_queued && occ_tagged)))
+        if (poll_mail && hits_tagged && (!occ_in_flight || (occ_queued && occ_tagged)))
             got = mail_wait(&g->mail->hits, occ_in_flight ? &g->mail->occupied : nullptr, mtag, 5.0);
         if (!got) VX_HIP(hipStreamSynchronize(s));
         const unsigned long long hits = g->mail->hits & kMailValue;
