@@ -451,13 +451,15 @@ vx_status setup_launch(const vx_mesh* m, const vx::GridParams& g, int sat, uint6
     return VX_OK;
 }
 
-vx_status setup_finish(uint32_t ntri, DevBuf& ubase, DevBuf& btri, Mail* mail, hipStream_t s, uint64_t* total_units, bool stream_is_drained = false)
+// btri_entries: entries of the block table a launch queued before the host knew the total has already filled (0: none)
+vx_status setup_finish(uint32_t ntri, DevBuf& ubase, DevBuf& btri, Mail* mail, hipStream_t s, uint64_t* total_units, bool stream_is_drained = false,
+                       uint64_t btri_entries = 0)
 {
     if (!stream_is_drained) VX_HIP(hipStreamSynchronize(s));
     const unsigned long long tot = mail->units & kMailValue;
     if (tot >= 0xFFFFFFFFull) return fail(VX_ERR_CAPACITY, "more than 2^32 candidate row segments: shard the mesh or the grid");
     *total_units = tot;
-    if (tot) {
+    if (tot && btri_entries < tot / 64 + 2) {
         VX_HIP(btri.ensure((size_t)(tot / 64 + 2) * 4));
         vx::launch_unit_blocks(ubase.as<uint32_t>(), ntri, (uint32_t)tot, btri.as<uint32_t>(), s);
     }
@@ -744,6 +746,7 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
     const unsigned long long mtag = (unsigned long long)g->mail_seq << 48;
     static const bool poll_mail = !(getenv("VOXHIP_POLL_MAIL") && atoi(getenv("VOXHIP_POLL_MAIL")) == 0);
     Extent ex;
+    uint64_t btri_entries = 0;  // entries of the block table filled by the launch queued ahead of the unit total
     bool setup_queued = false;
     size_t cleared = 0;
     if (!sharded_words && ntri > 0) {
@@ -754,6 +757,13 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
         vx::launch_bbox(mesh->dv, mesh->nv, ds->bbox_state, g->mail->bbox, ds->set_calls, s, vs, &ds->dgrid);
         bool units_tagged = false;
         VX_TRY(setup_launch(mesh, gp, o.sat_variant, tb, ntri, 0, 0, g->recs, g->units, g->ubase, g->scantmp, g->mail, s, &ds->dgrid, mtag, &units_tagged));
+        // the block table of the units: queued now, for as many blocks as the handle's table from the previous build holds, so that
+        // it runs while the host waits for the unit total (redone by setup_finish should the table turn out too small)
+        if (g->btri.p && g->btri.cap >= 64) {
+            btri_entries = g->btri.cap / 4;
+            if (btri_entries > 0x3FFFFFFull) btri_entries = 0x3FFFFFFull;
+            vx::launch_unit_blocks(g->ubase.as<uint32_t>(), ntri, (uint32_t)((btri_entries - 2) * 64), g->btri.as<uint32_t>(), s, (uint32_t)btri_entries);
+        }
         if (g->words.p) {
             VX_HIP(hipMemsetAsync(g->words.p, 0, g->words.cap, s));
             cleared = g->words.cap;
@@ -790,7 +800,7 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
     uint64_t U = 0;
     if (setup_queued) {
         if (!mask_is_clear) VX_HIP(hipMemsetAsync(g->words.p, 0, mask_bytes, s));
-        VX_TRY(setup_finish(ntri, g->ubase, g->btri, g->mail, s, &U, /*stream_is_drained=*/true));
+        VX_TRY(setup_finish(ntri, g->ubase, g->btri, g->mail, s, &U, /*stream_is_drained=*/true, btri_entries));
     } else {
         // z slab that contains the voxels of words [wb, we)
         const uint64_t XY = ex.dim[0] * ex.dim[1];

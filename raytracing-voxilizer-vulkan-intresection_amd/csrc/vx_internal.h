@@ -70,7 +70,7 @@ bool launch_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, bool popcoun
 // K2: triangle/voxel overlap over all work units; ORs hits into `words` (only words in [wb,we)), optionally
 // stores each unit's 32-bit hit mask (unit_mask) for the ordered emitters; adds the hit count to *set_calls.
 // block_tri (optional): per 256-unit block the triangle of its first unit (launch_unit_blocks), enables LDS staging.
-void launch_unit_blocks(const uint32_t* unit_base, uint32_t ntri, uint32_t total_units, uint32_t* block_tri, hipStream_t s);
+void launch_unit_blocks(const uint32_t* unit_base, uint32_t ntri, uint32_t total_units, uint32_t* block_tri, hipStream_t s, uint32_t cap_blocks = 0xFFFFFFFFu);
 void launch_voxelize(const TriRec* recs, const uint32_t* unit_base, const uint32_t* block_tri, uint32_t ntri, const GridParams& g,
                      int sat_variant, uint32_t* words, uint64_t wb, uint64_t we, uint32_t* unit_mask, unsigned long long* set_calls,
                      hipStream_t s);

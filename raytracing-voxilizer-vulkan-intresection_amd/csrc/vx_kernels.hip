@@ -577,12 +577,13 @@ constexpr uint32_t kUnitBlockLog2 = 6;
 // largest t with unit_base[t] <= 64 b; triangles without units share their base with the next one and are skipped by taking
 // the LAST such t).  The previous form -- one thread per triangle writing the blocks it spans -- serialised on the few
 // triangles that span hundreds of blocks.
-__global__ __launch_bounds__(256) void k_unit_blocks(const uint32_t* __restrict__ unit_base, uint32_t ntri, uint32_t* __restrict__ block_tri)
+__global__ __launch_bounds__(256) void k_unit_blocks(const uint32_t* __restrict__ unit_base, uint32_t ntri, uint32_t* __restrict__ block_tri,
+                                                     uint32_t cap_blocks /*entries block_tri can hold*/)
 {
     const uint32_t U = unit_base[ntri];
     const uint32_t nUB = (U + 63u) >> kUnitBlockLog2;
     const uint32_t b = blockIdx.x * 256u + threadIdx.x;
-    if (b >= nUB) return;
+    if (b >= nUB || b >= cap_blocks) return;
     const uint32_t u = b << kUnitBlockLog2;
     uint32_t lo = 0, hi = ntri;  // unit_base[lo] <= u < unit_base[hi]
     while (hi - lo > 1) {
@@ -592,11 +593,13 @@ __global__ __launch_bounds__(256) void k_unit_blocks(const uint32_t* __restrict_
     block_tri[b] = lo;
 }
 
-void launch_unit_blocks(const uint32_t* unit_base, uint32_t ntri, uint32_t total_units, uint32_t* block_tri, hipStream_t s)
+// total_units: the host's figure -- or, for a launch queued before the host knows it, the most the table can describe (the kernel
+// reads the real total from unit_base[ntri] and never writes at or beyond cap_blocks)
+void launch_unit_blocks(const uint32_t* unit_base, uint32_t ntri, uint32_t total_units, uint32_t* block_tri, hipStream_t s, uint32_t cap_blocks)
 {
-    const uint32_t nUB = (total_units + 63u) >> kUnitBlockLog2;
+    const uint32_t nUB = (uint32_t)(((uint64_t)total_units + 63u) >> kUnitBlockLog2);
     if (!ntri || !nUB) return;
-    VX_KL(k_unit_blocks, dim3((nUB + 255) / 256), dim3(256), 0, s, unit_base, ntri, block_tri);
+    VX_KL(k_unit_blocks, dim3((nUB + 255) / 256), dim3(256), 0, s, unit_base, ntri, block_tri, cap_blocks);
 }
 
 #ifdef VX_VOX_DEBUG
