@@ -723,3 +723,35 @@ def test_vec_list_bound_to_caller_buffer(gpu):
     g.bind_aabbs_device(None, 0)
     g.revoxelize(mesh, np.float32(0.031))
     assert g.aabbs().tobytes() == oracle.build_vec(v, t, np.float32(0.031)).tobytes()
+
+
+def test_rebuilds_alternating_meshes_same_grid(gpu):
+    """Forty rebuilds in ONE handle, alternating between a mesh and a subset of it that spans the same bounding box (same grid,
+    same bitmask addresses, fewer bits), both flavours.  The voxelizer skips an atomicOr when a plain load already shows the bits
+    set: a line of the PREVIOUS build surviving in a cache would show bits that the fresh mask does not have and drop them.  Also
+    exercises the polled mailbox totals (every build has its own sequence tag) and the block table queued ahead of the unit total
+    (the subset has fewer units than the table of the build before it)."""
+    v, t = vx_scenes.scene("blob70k")
+    vs = np.float32(2.0 / 128)
+    keep = np.zeros(len(t), bool)
+    keep[::3] = True
+    # keep every triangle that touches an extreme vertex, so that both meshes have the same bounding box
+    ext = set(np.argmin(v, axis=0).tolist() + np.argmax(v, axis=0).tolist())
+    keep |= np.isin(t, list(ext)).any(axis=1)
+    tb = t[keep]
+    for kind in (gpu.GRID_BOOL, gpu.GRID_VEC):
+        ref = []
+        for tri in (t, tb):
+            ow, calls, gi = oracle.build_bool(v, tri, vs)
+            ref.append((ow, calls, gi))
+        assert ref[0][2]["dim"] == ref[1][2]["dim"] and not np.array_equal(ref[0][0], ref[1][0])
+        meshes = [gpu.Mesh.from_arrays(v, t), gpu.Mesh.from_arrays(v, tb)]
+        g = gpu.Grid.voxelize(meshes[0], vs, kind)
+        for k in range(40):
+            which = (k + 1) % 2 if k % 5 else k % 2   # A B A B ... with an occasional repeat
+            g.revoxelize(meshes[which], vs)
+            ow, calls, gi = ref[which]
+            assert np.array_equal(g.bitmask(), ow), "rebuild %d (mesh %d, kind %d)" % (k, which, kind)
+            if k % 7 == 0:
+                d = g.describe()
+                assert d["set_calls"] == calls and d["occupied"] == int(np.unpackbits(ow.view(np.uint8)).sum())
