@@ -459,9 +459,12 @@ __device__ __forceinline__ void trim_axis(float a0, float a1, float a2, float or
 
 __global__ __launch_bounds__(256) void k_tri_setup(const float* __restrict__ verts, const int32_t* __restrict__ idx, uint64_t tri_begin,
                                                    uint32_t ntri, GridParams g, float vsize, uint32_t zlo, uint32_t zhi,
-                                                   TriRec* __restrict__ recs, uint32_t* __restrict__ units, const DevGrid* __restrict__ dgrid)
+                                                   TriRec* __restrict__ recs, uint32_t* __restrict__ units, const DevGrid* __restrict__ dgrid,
+                                                   uint4* __restrict__ clear /*optional: 16-byte pieces to zero*/, uint64_t clear_n)
 {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    // (optional) the build's bitmask is cleared by this kernel's threads, beside their own work: a launch and its gap less
+    for (uint64_t i = t; i < clear_n; i += (uint64_t)gridDim.x * 256u) clear[i] = make_uint4(0u, 0u, 0u, 0u);
     if (t >= ntri) return;
     if (dgrid) {  // origin and dims from the bbox kernel queued in front (the host has not seen them yet); whole grid in z
 #pragma unroll
@@ -504,12 +507,13 @@ __global__ __launch_bounds__(256) void k_tri_setup(const float* __restrict__ ver
 }
 
 void launch_tri_setup(const float* verts, const int32_t* idx, uint64_t tri_begin, uint32_t ntri, const GridParams& g, int sat_variant,
-                      uint32_t zlo, uint32_t zhi, TriRec* recs, uint32_t* units, hipStream_t s, const DevGrid* dgrid)
+                      uint32_t zlo, uint32_t zhi, TriRec* recs, uint32_t* units, hipStream_t s, const DevGrid* dgrid, void* clear, uint64_t clear_bytes)
 {
     if (!ntri) return;
     // serial driver: voxelSize = halfVoxelSize.x * 2.0f (VoxelBuilder.hpp:173); threaded driver: vSize = voxelSize (:500)
     const float vsize = sat_variant == 0 ? g.half * 2.0f : g.vs;
-    VX_KL(k_tri_setup, dim3((ntri + 255) / 256), dim3(256), 0, s, verts, idx, tri_begin, ntri, g, vsize, zlo, zhi, recs, units, dgrid);
+    VX_KL(k_tri_setup, dim3((ntri + 255) / 256), dim3(256), 0, s, verts, idx, tri_begin, ntri, g, vsize, zlo, zhi, recs, units, dgrid,
+          reinterpret_cast<uint4*>(clear), clear ? clear_bytes / 16 : 0);
 }
 
 // ------------------------------------------------------------------------------------------------------------
