@@ -439,13 +439,14 @@ constexpr uint64_t kMaxVoxels = 1ull << 37;  // 16 GiB of bitmask
 // the caller can queue work that does not depend on the unit count (clearing the bitmask) before the host waits for it.
 vx_status setup_launch(const vx_mesh* m, const vx::GridParams& g, int sat, uint64_t tb, uint32_t ntri, uint32_t zlo, uint32_t zhi, DevBuf& recs,
                        DevBuf& units, DevBuf& ubase, DevBuf& scantmp, Mail* mail, hipStream_t s, const vx::DevGrid* dgrid = nullptr,
-                       unsigned long long mail_tag = 0, bool* tagged = nullptr, void* clear = nullptr, uint64_t clear_bytes = 0)
+                       unsigned long long mail_tag = 0, bool* tagged = nullptr, void* clear = nullptr, uint64_t clear_bytes = 0,
+                       uint64_t shard_wb = 0, uint64_t shard_we = 0)
 {
     VX_HIP(recs.ensure((size_t)ntri * sizeof(vx::TriRec) + 64));
     VX_HIP(units.ensure(((size_t)ntri + 1) * 4));
     VX_HIP(ubase.ensure(((size_t)ntri + 2) * 4));
     VX_HIP(ensure_scan_tmp(scantmp, vx::scan_tmp_bytes(ntri), s));
-    vx::launch_tri_setup(m->dv, m->di, tb, ntri, g, sat, zlo, zhi, recs.as<vx::TriRec>(), units.as<uint32_t>(), s, dgrid, clear, clear_bytes);
+    vx::launch_tri_setup(m->dv, m->di, tb, ntri, g, sat, zlo, zhi, recs.as<vx::TriRec>(), units.as<uint32_t>(), s, dgrid, clear, clear_bytes, shard_wb, shard_we);
     const bool tg = vx::launch_scan_u32(units.as<uint32_t>(), ubase.as<uint32_t>(), ntri, false, scantmp.p, &mail->units, s, true, mail_tag);
     if (tagged) *tagged = tg && mail_tag != 0;
     return VX_OK;
@@ -749,7 +750,7 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
     uint64_t btri_entries = 0;  // entries of the block table filled by the launch queued ahead of the unit total
     bool setup_queued = false;
     size_t cleared = 0;
-    if (!sharded_words && ntri > 0) {
+    if (ntri > 0) {  // (a word shard's z slab is derived from the device-side dims by the record kernel itself)
         vx::GridParams gp{};
         const float zero3[3] = {0.f, 0.f, 0.f};
         const uint64_t zdim[3] = {0, 0, 0};
@@ -760,7 +761,8 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
         // them (at most 256 bytes each), by a memset behind the block table otherwise
         const bool clear_in_setup = g->words.p && (g->words.cap % 16) == 0 && g->words.cap / 256 <= (size_t)ntri;
         VX_TRY(setup_launch(mesh, gp, o.sat_variant, tb, ntri, 0, 0, g->recs, g->units, g->ubase, g->scantmp, g->mail, s, &ds->dgrid, mtag, &units_tagged,
-                            clear_in_setup ? g->words.p : nullptr, clear_in_setup ? g->words.cap : 0));
+                            clear_in_setup ? g->words.p : nullptr, clear_in_setup ? g->words.cap : 0, sharded_words ? o.word_begin : 0,
+                            sharded_words ? o.word_end : 0));
         if (clear_in_setup) cleared = g->words.cap;
         // the block table of the units: queued now, for as many blocks as the handle's table from the previous build holds, so that
         // it runs while the host waits for the unit total (redone by setup_finish should the table turn out too small)

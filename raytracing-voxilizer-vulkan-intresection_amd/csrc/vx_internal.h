@@ -58,7 +58,8 @@ void launch_bbox(const float* verts, uint64_t nverts, unsigned long long* state7
 // K2a: per-triangle record + number of row-segment work units; zlo/zhi clamp the candidate box to a z slab.
 void launch_tri_setup(const float* verts, const int32_t* idx, uint64_t tri_begin, uint32_t ntri, const GridParams& g,
                       int sat_variant, uint32_t zlo, uint32_t zhi, TriRec* recs, uint32_t* units, hipStream_t s, const DevGrid* dgrid = nullptr,
-                      void* clear = nullptr /*optional: a 16-byte aligned buffer the kernel zeroes beside its own work*/, uint64_t clear_bytes = 0);
+                      void* clear = nullptr /*optional: a 16-byte aligned buffer the kernel zeroes beside its own work*/, uint64_t clear_bytes = 0,
+                      uint64_t shard_wb = 0, uint64_t shard_we = 0 /*with dgrid: derive zlo / zhi on the device from the word shard (0, 0: whole grid)*/);
 
 // exclusive scan of n uint32 (or of their popcounts) into out[0..n] (out[n] = total, saturating check via *total64)
 size_t scan_tmp_bytes(uint64_t n);

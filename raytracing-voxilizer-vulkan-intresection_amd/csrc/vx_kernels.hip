@@ -460,7 +460,8 @@ __device__ __forceinline__ void trim_axis(float a0, float a1, float a2, float or
 __global__ __launch_bounds__(256) void k_tri_setup(const float* __restrict__ verts, const int32_t* __restrict__ idx, uint64_t tri_begin,
                                                    uint32_t ntri, GridParams g, float vsize, uint32_t zlo, uint32_t zhi,
                                                    TriRec* __restrict__ recs, uint32_t* __restrict__ units, const DevGrid* __restrict__ dgrid,
-                                                   uint4* __restrict__ clear /*optional: 16-byte pieces to zero*/, uint64_t clear_n)
+                                                   uint4* __restrict__ clear /*optional: 16-byte pieces to zero*/, uint64_t clear_n,
+                                                   uint64_t shard_wb, uint64_t shard_we /*with dgrid: the bitmask words of a sharded build (0, 0: all)*/)
 {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     // (optional) the build's bitmask is cleared by this kernel's threads, beside their own work: a launch and its gap less
@@ -471,6 +472,15 @@ __global__ __launch_bounds__(256) void k_tri_setup(const float* __restrict__ ver
         for (int a = 0; a < 3; ++a) { g.org[a] = dgrid->org[a]; g.dim[a] = dgrid->dim[a]; }
         zlo = 0u;
         zhi = g.dim[2];
+        if (shard_we) {  // the z slab that holds the voxels of words [shard_wb, shard_we): the host's own arithmetic (vx_voxelize_into)
+            const uint64_t XY = (uint64_t)g.dim[0] * g.dim[1];
+            if (XY) {
+                zlo = (uint32_t)((shard_wb * 32ull) / XY);
+                const uint64_t zh = (shard_we * 32ull + XY - 1ull) / XY;
+                zhi = zh > g.dim[2] ? g.dim[2] : (uint32_t)zh;
+                if (zlo > zhi) zlo = zhi;
+            }
+        }
     }
     const int32_t* ip = idx + 3 * (tri_begin + t);
     TriRec r;
@@ -507,13 +517,13 @@ __global__ __launch_bounds__(256) void k_tri_setup(const float* __restrict__ ver
 }
 
 void launch_tri_setup(const float* verts, const int32_t* idx, uint64_t tri_begin, uint32_t ntri, const GridParams& g, int sat_variant,
-                      uint32_t zlo, uint32_t zhi, TriRec* recs, uint32_t* units, hipStream_t s, const DevGrid* dgrid, void* clear, uint64_t clear_bytes)
+                      uint32_t zlo, uint32_t zhi, TriRec* recs, uint32_t* units, hipStream_t s, const DevGrid* dgrid, void* clear, uint64_t clear_bytes, uint64_t shard_wb, uint64_t shard_we)
 {
     if (!ntri) return;
     // serial driver: voxelSize = halfVoxelSize.x * 2.0f (VoxelBuilder.hpp:173); threaded driver: vSize = voxelSize (:500)
     const float vsize = sat_variant == 0 ? g.half * 2.0f : g.vs;
     VX_KL(k_tri_setup, dim3((ntri + 255) / 256), dim3(256), 0, s, verts, idx, tri_begin, ntri, g, vsize, zlo, zhi, recs, units, dgrid,
-          reinterpret_cast<uint4*>(clear), clear ? clear_bytes / 16 : 0);
+          reinterpret_cast<uint4*>(clear), clear ? clear_bytes / 16 : 0, shard_wb, shard_we);
 }
 
 // ------------------------------------------------------------------------------------------------------------
