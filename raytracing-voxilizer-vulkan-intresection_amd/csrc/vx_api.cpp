@@ -296,6 +296,7 @@ struct vx_grid {
     uint64_t occupied = 0, set_calls = 0, host_set_calls = 0;
     uint64_t vec_count = 0;
     uint32_t mail_seq = 0;  // sequence tag of the totals the current build writes to the mailbox
+    unsigned long long occ_tag = 0;  // tag of the word-prefix scan whose total (the occupied count) is in flight; 0: untagged
     int trace_phase = 0;  // which of Small::trace_counters[0..1] the next ray launch draws its work from (the launch clears the other)
     // VX_GRID_VEC: the caller's own list buffer (vx_grid_bind_aabbs_device); builds emit straight into it when it is large enough
     vx_aabb* bound = nullptr;
@@ -474,10 +475,15 @@ vx_status prefix_launch(vx_grid* g, bool* pending, unsigned long long tag = 0, b
     *pending = !g->occupied_known;
     if (tagged) *tagged = false;
     if (g->prefix_valid) return VX_OK;
+    if (!tag) {  // a scan outside a build: its own sequence tag
+        g->mail_seq = (g->mail_seq % 0xFFFFu) + 1u;
+        tag = (unsigned long long)g->mail_seq << 48;
+    }
     VX_HIP(g->wprefix.ensure((size_t)(g->g.nwords + 2) * 4));
     VX_HIP(ensure_scan_tmp(g->scantmp, vx::scan_tmp_bytes(g->g.nwords), g->stream));
     const bool tg = vx::launch_scan_u32(g->words.as<uint32_t>(), g->wprefix.as<uint32_t>(), g->g.nwords, true, g->scantmp.p, &g->mail->occupied, g->stream, true, tag);
-    if (tagged) *tagged = tg && tag != 0;
+    if (tagged) *tagged = tg;
+    g->occ_tag = tg ? tag : 0;  // what the host may poll the mailbox for instead of draining the stream (prefix_finish)
     g->prefix_valid = true;
     g->occupied_known = false;
     *pending = true;
@@ -487,7 +493,8 @@ vx_status prefix_launch(vx_grid* g, bool* pending, unsigned long long tag = 0, b
 vx_status prefix_finish(vx_grid* g, bool pending)
 {
     if (!pending || g->occupied_known) return VX_OK;
-    VX_HIP(hipStreamSynchronize(g->stream));
+    static const bool poll = !(getenv("VOXHIP_POLL_MAIL") && atoi(getenv("VOXHIP_POLL_MAIL")) == 0);
+    if (!(poll && g->occ_tag && mail_wait(&g->mail->occupied, nullptr, g->occ_tag, 5.0))) VX_HIP(hipStreamSynchronize(g->stream));
     const unsigned long long tot = g->mail->occupied & kMailValue;
     if (tot >= 0xFFFFFFFFull) return fail(VX_ERR_CAPACITY, "more than 2^32 occupied voxels");
     g->occupied = tot;
