@@ -288,7 +288,7 @@ struct vx_grid {
     float bbmin[3] = {0, 0, 0}, bbmax[3] = {0, 0, 0}, bbc[3] = {0, 0, 0};
     uint64_t triangles = 0;
     uint32_t cdim[3] = {0, 0, 0}, c2dim[3] = {0, 0, 0};
-    DevBuf words, cwords, c2words, bricks, idxtmp, ttmp, camera, wprefix, recs, units, ubase, btri, umask, hbase, scantmp, small, vec, matids, mattmp;
+    DevBuf words, cwords, c2words, bricks, idxtmp, ttmp, camera, wprefix, wsel /*word of every 1024th occupied voxel (prefix scan)*/, recs, units, ubase, btri, umask, hbase, scantmp, small, vec, matids, mattmp;
     std::vector<vx_material> materials;  // m_materials: distinct values in first-use order (VX_VOXELIZE_MATERIALS builds only)
     uint64_t mat_count = 0;              // entries of matids
     bool has_materials = false;
@@ -296,6 +296,7 @@ struct vx_grid {
     uint64_t occupied = 0, set_calls = 0, host_set_calls = 0;
     uint64_t vec_count = 0;
     uint32_t mail_seq = 0;  // sequence tag of the totals the current build writes to the mailbox
+    bool sel_valid = false;  // wsel belongs to the current word prefix
     unsigned long long occ_tag = 0;  // tag of the word-prefix scan whose total (the occupied count) is in flight; 0: untagged
     int trace_phase = 0;  // which of Small::trace_counters[0..1] the next ray launch draws its work from (the launch clears the other)
     // VX_GRID_VEC: the caller's own list buffer (vx_grid_bind_aabbs_device); builds emit straight into it when it is large enough
@@ -307,18 +308,18 @@ struct vx_grid {
     void set_dev(int d)
     {
         device = d;
-        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &idxtmp, &ttmp, &camera, &wprefix, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec, &matids, &mattmp}) b->dev = d;
+        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &idxtmp, &ttmp, &camera, &wprefix, &wsel, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec, &matids, &mattmp}) b->dev = d;
     }
     // the stream this handle queues work on; the pool orders the reuse of released blocks by it
     void set_stream(hipStream_t st)
     {
         if (st != stream && words.p) (void)hipStreamSynchronize(stream);  // work queued on the old stream must not outlive the switch
         stream = st;
-        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &idxtmp, &ttmp, &camera, &wprefix, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec, &matids, &mattmp}) b->stream = st;
+        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &idxtmp, &ttmp, &camera, &wprefix, &wsel, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec, &matids, &mattmp}) b->stream = st;
     }
     void release_all()
     {
-        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &idxtmp, &ttmp, &camera, &wprefix, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec, &matids, &mattmp}) b->release();
+        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &idxtmp, &ttmp, &camera, &wprefix, &wsel, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec, &matids, &mattmp}) b->release();
         if (mail) (void)hipHostFree(mail);
         mail = nullptr;
     }
@@ -480,8 +481,11 @@ vx_status prefix_launch(vx_grid* g, bool* pending, unsigned long long tag = 0, b
         tag = (unsigned long long)g->mail_seq << 48;
     }
     VX_HIP(g->wprefix.ensure((size_t)(g->g.nwords + 2) * 4));
+    VX_HIP(g->wsel.ensure((size_t)(g->g.nwords / 32 + 4) * 4));  // at most 32 nwords / 1024 chunks of 1024 records
     VX_HIP(ensure_scan_tmp(g->scantmp, vx::scan_tmp_bytes(g->g.nwords), g->stream));
-    const bool tg = vx::launch_scan_u32(g->words.as<uint32_t>(), g->wprefix.as<uint32_t>(), g->g.nwords, true, g->scantmp.p, &g->mail->occupied, g->stream, true, tag);
+    const bool tg = vx::launch_scan_u32(g->words.as<uint32_t>(), g->wprefix.as<uint32_t>(), g->g.nwords, true, g->scantmp.p, &g->mail->occupied, g->stream, true, tag,
+                                        g->wsel.as<uint32_t>());
+    g->sel_valid = tg;  // (the three-pass scan does not write it)
     if (tagged) *tagged = tg;
     g->occ_tag = tg ? tag : 0;  // what the host may poll the mailbox for instead of draining the stream (prefix_finish)
     g->prefix_valid = true;
@@ -1235,7 +1239,7 @@ vx_status vx_grid_aabbs_device(const vx_grid* gc, vx_aabb* dev_out, uint64_t cap
     bool pending = false;
     VX_TRY(prefix_launch(g, &pending));
     if (cap && dev_out && (pending || g->occupied))
-        vx::launch_emit_bool_aabbs(g->words.as<uint32_t>(), g->wprefix.as<uint32_t>(), g->g, dev_out, cap, g->stream);
+        vx::launch_emit_bool_aabbs(g->words.as<uint32_t>(), g->wprefix.as<uint32_t>(), g->g, dev_out, cap, g->stream, g->sel_valid ? g->wsel.as<uint32_t>() : nullptr);
     VX_TRY(prefix_finish(g, pending));
     if (count) *count = g->occupied;
     VX_HIP(hipGetLastError());
@@ -1262,7 +1266,7 @@ vx_status vx_grid_aabbs(const vx_grid* gc, vx_aabb* host_out, uint64_t cap, uint
     tmp.dev = g->device;
     tmp.stream = g->stream;
     VX_HIP(tmp.ensure((size_t)m * sizeof(vx_aabb)));
-    vx::launch_emit_bool_aabbs(g->words.as<uint32_t>(), g->wprefix.as<uint32_t>(), g->g, tmp.as<vx_aabb>(), m, g->stream);
+    vx::launch_emit_bool_aabbs(g->words.as<uint32_t>(), g->wprefix.as<uint32_t>(), g->g, tmp.as<vx_aabb>(), m, g->stream, g->sel_valid ? g->wsel.as<uint32_t>() : nullptr);
     hipError_t e = hipMemcpyAsync(host_out, tmp.p, (size_t)m * sizeof(vx_aabb), hipMemcpyDeviceToHost, g->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
     tmp.release();

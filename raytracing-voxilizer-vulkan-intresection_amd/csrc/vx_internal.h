@@ -67,7 +67,8 @@ size_t scan_tmp_bytes(uint64_t n);
 // total_tag (bits 48..63 only): OR-ed into *total64 by the single-pass kernel, so that a host polling a pinned mailbox word can tell
 // this scan's total from an older one; returns whether the tag was applied (false: the three-pass path, *total64 is the bare total).
 bool launch_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, bool popcount_input, void* tmp,
-                     unsigned long long* total64, hipStream_t s, bool tmp_is_zero = false, unsigned long long total_tag = 0);
+                     unsigned long long* total64, hipStream_t s, bool tmp_is_zero = false, unsigned long long total_tag = 0,
+                     uint32_t* sel1024 = nullptr /*optional (single-pass kernel only, values <= 1024): sel1024[c] = the element whose range holds c * 1024*/);
 
 // K2: triangle/voxel overlap over all work units; ORs hits into `words` (only words in [wb,we)), optionally
 // stores each unit's 32-bit hit mask (unit_mask) for the ordered emitters; adds the hit count to *set_calls.
@@ -92,7 +93,7 @@ void launch_mat_ids_calls(const TriRec* recs, const uint32_t* unit_base, const u
 
 // K4: bitmask -> ordered AABB list (word_prefix = exclusive scan of popcounts, nwords+1 entries)
 void launch_emit_bool_aabbs(const uint32_t* words, const uint32_t* word_prefix, const GridParams& g, vx_aabb* out,
-                            uint64_t capacity, hipStream_t s);
+                            uint64_t capacity, hipStream_t s, const uint32_t* sel1024 = nullptr /*from the prefix scan: the word of every 1024th record*/);
 // AABBs from sorted Morton items (Octree::getAabbs)
 void launch_emit_morton_aabbs(const uint64_t* items, uint64_t n, const float root_min[3], float vs, vx_aabb* out, hipStream_t s);
 

@@ -299,7 +299,8 @@ constexpr int kOneBlock = VX_SCAN_BLOCK, kOneItems = VX_SCAN_ITEMS, kOneTile = k
 template <bool POPC>
 __global__ __launch_bounds__(kOneBlock) void k_scan_onepass(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t n,
                                                            unsigned long long* status /*[0]: ticket, [1]: finished tiles, [2 + tile]: state*/, uint32_t ntiles,
-                                                           unsigned long long* total, unsigned long long total_tag /*OR-ed into *total: bits 48..63*/)
+                                                           unsigned long long* total, unsigned long long total_tag /*OR-ed into *total: bits 48..63*/,
+                                                           uint32_t* __restrict__ sel /*optional: sel[c] = index of the element whose range [pre, pre + v) holds c * 1024*/)
 {
     __shared__ unsigned wsum[kOneBlock / 64];
     __shared__ unsigned tile_s;
@@ -380,11 +381,23 @@ __global__ __launch_bounds__(kOneBlock) void k_scan_onepass(const uint32_t* __re
             uint4 a;
             a.x = pre; pre += v[4 * q]; a.y = pre; pre += v[4 * q + 1]; a.z = pre; pre += v[4 * q + 2]; a.w = pre; pre += v[4 * q + 3];
             *reinterpret_cast<uint4*>(out + base + 4 * q) = a;
+            if (sel) {  // (values of at most 1024: an element's range holds at most one multiple of 1024)
+                const uint32_t p4[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t ve = v[4 * q + e], c = (p4[e] + ve - 1u) >> 10;
+                    if (ve && (c << 10) >= p4[e]) sel[c] = (uint32_t)(base + 4 * q + e);
+                }
+            }
         }
     } else {
 #pragma unroll
         for (int j = 0; j < kOneItems; ++j) {
             if (base + j <= n) out[base + j] = pre;
+            if (sel && v[j] && base + j < n) {
+                const uint32_t c = (pre + v[j] - 1u) >> 10;
+                if ((c << 10) >= pre) sel[c] = (uint32_t)(base + j);
+            }
             pre += v[j];
         }
     }
@@ -404,7 +417,7 @@ __global__ __launch_bounds__(kOneBlock) void k_scan_onepass(const uint32_t* __re
 size_t scan_tmp_bytes(uint64_t n) { return (size_t)(((n + 1) + kScanTile - 1) / kScanTile + 4) * sizeof(unsigned long long); }
 
 bool launch_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, bool popcount_input, void* tmp, unsigned long long* total64,
-                     hipStream_t s, bool tmp_is_zero, unsigned long long total_tag)
+                     hipStream_t s, bool tmp_is_zero, unsigned long long total_tag, uint32_t* sel1024)
 {
     const uint32_t nblocks = (uint32_t)(((n + 1) + kScanTile - 1) / kScanTile);
     unsigned long long* status = (unsigned long long*)tmp;
@@ -413,8 +426,8 @@ bool launch_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, bool popcoun
     if (!three_pass && aligned) {
         const uint32_t ntiles = (uint32_t)(((n + 1) + kOneTile - 1) / kOneTile);
         if (!tmp_is_zero) (void)hipMemsetAsync(status, 0, (size_t)(ntiles + 2) * sizeof(unsigned long long), s);
-        if (popcount_input) VX_KL(k_scan_onepass<true>, dim3(ntiles), dim3(kOneBlock), 0, s, in, out, n, status, ntiles, total64, total_tag);
-        else VX_KL(k_scan_onepass<false>, dim3(ntiles), dim3(kOneBlock), 0, s, in, out, n, status, ntiles, total64, total_tag);
+        if (popcount_input) VX_KL(k_scan_onepass<true>, dim3(ntiles), dim3(kOneBlock), 0, s, in, out, n, status, ntiles, total64, total_tag, sel1024);
+        else VX_KL(k_scan_onepass<false>, dim3(ntiles), dim3(kOneBlock), 0, s, in, out, n, status, ntiles, total64, total_tag, sel1024);
         return true;
     }
     unsigned long long* sums = status;
@@ -931,8 +944,10 @@ __device__ __forceinline__ uint64_t upper_word(const uint32_t* __restrict__ pre,
     return lo;
 }
 
+// `sel` (optional, written by the prefix scan): sel[c] = the word that holds output record 1024 c -- without it every workgroup finds
+// its word range by two binary searches of the prefix array in global memory: 44 dependent loads, 30 of the kernel's 52 us.
 __global__ __launch_bounds__(256) void k_emit_bool(const uint32_t* __restrict__ words, const uint32_t* __restrict__ word_prefix, GridParams g,
-                                                   vx_aabb* __restrict__ out, uint64_t capacity)
+                                                   vx_aabb* __restrict__ out, uint64_t capacity, const uint32_t* __restrict__ sel)
 {
     __shared__ uint32_t s_pre[kEmitStage + 1];
     __shared__ uint32_t s_word[kEmitStage];
@@ -944,8 +959,11 @@ __global__ __launch_bounds__(256) void k_emit_bool(const uint32_t* __restrict__ 
         const uint32_t o_first = (uint32_t)ob;
         const uint32_t o_last = (uint32_t)((ob + kEmitOut < limit ? ob + kEmitOut : limit) - 1);
         // word range of this output range (uniform: every lane runs the same search, the loads are broadcast)
-        const uint64_t w_lo = upper_word(word_prefix, 0, g.nwords, o_first);
-        const uint64_t w_hi = upper_word(word_prefix, w_lo, g.nwords, o_last);
+        static_assert(kEmitOut == 1024, "sel is sampled every 1024 records");
+        const uint64_t w_lo = sel ? (uint64_t)sel[ob >> 10] : upper_word(word_prefix, 0, g.nwords, o_first);
+        // a full chunk ends where the next one begins: the word that holds record o_last + 1 is at or behind the one that holds o_last
+        const bool next_known = sel && (uint64_t)o_last + 1 == ob + kEmitOut && (uint64_t)o_last + 1 < total;
+        const uint64_t w_hi = next_known ? (uint64_t)sel[(ob >> 10) + 1] : upper_word(word_prefix, w_lo, g.nwords, o_last);
         const uint32_t nw = (uint32_t)(w_hi - w_lo + 1);
         const bool staged = nw <= kEmitStage;
         if (staged) {
@@ -993,12 +1011,12 @@ __global__ __launch_bounds__(256) void k_emit_bool(const uint32_t* __restrict__ 
 }
 
 void launch_emit_bool_aabbs(const uint32_t* words, const uint32_t* word_prefix, const GridParams& g, vx_aabb* out, uint64_t capacity,
-                            hipStream_t s)
+                            hipStream_t s, const uint32_t* sel1024)
 {
     if (!g.nwords || !capacity) return;
     // the grid is sized by the caller's capacity (the count is only known on the device); surplus workgroups exit at once
     const uint64_t nblk = (capacity + kEmitOut - 1) / kEmitOut;
-    VX_KL(k_emit_bool, dim3((unsigned)(nblk < 65536 ? nblk : 65536)), dim3(256), 0, s, words, word_prefix, g, out, capacity);
+    VX_KL(k_emit_bool, dim3((unsigned)(nblk < 65536 ? nblk : 65536)), dim3(256), 0, s, words, word_prefix, g, out, capacity, sel1024);
 }
 
 // Octree::getAabbs: DFS over the node array visits items in sorted order (octTree.hpp:374-392); decode + AABB per item.
