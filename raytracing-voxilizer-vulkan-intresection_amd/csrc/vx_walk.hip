@@ -226,6 +226,13 @@ struct WalkLane {
     uint32_t sm;             // bit s: slab s of the brick may hold a cell the ray touches (word & brick-level rectangle != 0)
 };
 
+// the low byte of m in all eight bytes (two shift-ors; a 64-bit multiply by 0x0101010101010101 is three quarter-rate instructions)
+__device__ __forceinline__ unsigned long long rep8(uint32_t m)
+{
+    uint32_t r = m | (m << 8);
+    r |= r << 16;
+    return ((unsigned long long)r << 32) | r;
+}
 __device__ __forceinline__ float sel3f(int p, float a, float b, float c) { return p == 0 ? a : (p == 1 ? b : c); }
 __device__ __forceinline__ unsigned long long sel8(int i, unsigned long long a, unsigned long long b, unsigned long long c, unsigned long long d,
                                                    unsigned long long e, unsigned long long f, unsigned long long g, unsigned long long h)
@@ -477,7 +484,7 @@ __device__ __forceinline__ void walk_fetch_brick(WalkLane<IdxT>& R, const WalkHo
     const int u0 = (int)(R.pu & 0xFFFFu), u1 = (int)(R.pu >> 16), v0 = (int)(R.pv & 0xFFFFu), v1 = (int)(R.pv >> 16);
     const int a0 = (u0 > bu ? u0 : bu) - bu, a1 = (u1 < bu + 7 ? u1 : bu + 7) - bu;  // columns of the brick slab's rectangle inside this brick
     const int b0 = (v0 > bv ? v0 : bv) - bv, b1 = (v1 < bv + 7 ? v1 : bv + 7) - bv;  // rows
-    const unsigned long long col = (unsigned long long)((2u << a1) - (1u << a0)) * 0x0101010101010101ull;
+    const unsigned long long col = rep8((2u << a1) - (1u << a0));
     const unsigned long long rect = col & (~0ull >> (8 * (7 - b1))) & (~0ull << (8 * b0));
     R.w0 = w01.x; R.w1 = w01.y; R.w2 = w23.x; R.w3 = w23.y; R.w4 = w45.x; R.w5 = w45.y; R.w6 = w67.x; R.w7 = w67.y;
     uint32_t sm = ((w01.x & rect) ? 1u : 0u) | ((w01.y & rect) ? 2u : 0u) | ((w23.x & rect) ? 4u : 0u) | ((w23.y & rect) ? 8u : 0u) |
@@ -572,7 +579,7 @@ __device__ __forceinline__ bool walk_step(WalkLane<IdxT>& R, const WalkHot& P, c
             a1 = a1 > 7 ? 7 : a1; b1 = b1 > 7 ? 7 : b1;
             unsigned long long cand = 0ull;
             if (a0 <= a1 && b0 <= b1) {
-                const unsigned long long col = (unsigned long long)((2u << a1) - (1u << a0)) * 0x0101010101010101ull;
+                const unsigned long long col = rep8((2u << a1) - (1u << a0));
                 cand = bits & col & (~0ull >> (8 * (7 - b1))) & (~0ull << (8 * b0));
             }
             if (cand) {
