@@ -647,6 +647,13 @@ struct __attribute__((aligned(16))) UnitStage {  // one wave's staging buffer
     uint32_t base[kStageTris];
 };
 constexpr uint32_t kStagesPerBlock = 2 * 4;  // double-buffered, four waves per 256-thread workgroup
+// Grid of k_voxelize: the 26 KiB of staging buffers let SIX workgroups live on a CU (160 KiB of LDS), so 256 CUs x 6 is one even,
+// fully resident set of persistent workgroups; with 256 x 8 the last quarter ran as a second, ragged round (k_voxelize 110 -> 104 us;
+// 5 per CU: 108, 7: 125).  The emission kernels, bound by their stores, are faster with the larger grid (42 vs 45 us).
+#ifndef VX_UNIT_BLOCKS
+#define VX_UNIT_BLOCKS (256 * 6)
+#endif
+constexpr unsigned kUnitBlocks = VX_UNIT_BLOCKS;
 
 // Asynchronous global -> LDS copies (gfx950 LDS-DMA: no VGPR destination).  The LDS destination of one wave-instruction is
 // lds_base + lane * size, so both images are lane-linear.
@@ -859,7 +866,7 @@ void launch_voxelize(const TriRec* recs, const uint32_t* unit_base, const uint32
                      uint32_t* words, uint64_t wb, uint64_t we, uint32_t* unit_mask, unsigned long long* set_calls, hipStream_t s)
 {
     if (!ntri) return;
-    const dim3 grid(kMaxBlocks), block(256);
+    const dim3 grid(kUnitBlocks), block(256);
     if (sat_variant == 0) {
         if (unit_mask) VX_KL((k_voxelize<true, true>), grid, block, 0, s, recs, unit_base, block_tri, ntri, g, words, wb, we, unit_mask, set_calls);
         else VX_KL((k_voxelize<true, false>), grid, block, 0, s, recs, unit_base, block_tri, ntri, g, words, wb, we, unit_mask, set_calls);
