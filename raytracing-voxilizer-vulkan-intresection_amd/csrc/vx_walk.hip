@@ -1084,7 +1084,7 @@ void launch_walk(const GridParams& g, const TraceMips& mips, const TraceIO& io, 
         // ray latencies whatever the batch; with somewhat fewer waves a lane sees at least ~4 rays and the same work drains from fewer
         // rays in flight (measured on the bench scene, 0.5M / 0.75M / 1M rays: -3 / -8 / -8 %; below ~0.4M rays, where a lane has at
         // most one or two rays anyway, the full width is faster, and from ~1.1M rays on the rule gives the full width).
-        if (n >= 400000ull && n / 1075ull < max_blocks) max_blocks = n / 1075ull;
+        if (n >= 400000ull && n / 1040ull < max_blocks) max_blocks = n / 1040ull;
         if (env_blocks > 0) max_blocks = (uint64_t)env_blocks;
         uint64_t nblk = (n + VX_W_BLOCK - 1) / VX_W_BLOCK;
         if (nblk > max_blocks) nblk = max_blocks;
