@@ -15,9 +15,17 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def run_bench(*args):
     env = dict(os.environ)
-    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env["MASTER_PORT"] = str(free_port())   # the rendezvous of --force-dist: never a fixed port on a shared box
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                        env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
