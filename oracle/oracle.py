@@ -10,10 +10,14 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libvxoracle.so")
+# VXORACLE_SO: load this build of the oracle instead of the in-tree one (tests/test_oracle_compilers.py compares the
+# results of several compilers / optimisation levels; nothing else sets it)
+_SO = os.environ.get("VXORACLE_SO") or os.path.join(_HERE, "libvxoracle.so")
 
 
 def build(force=False):
+    if os.environ.get("VXORACLE_SO"):
+        return _SO
     srcs = [os.path.join(_HERE, f) for f in ("vx_oracle.c", "vx_walk.c", "Makefile")]
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "libvxoracle.so"])
