@@ -61,6 +61,8 @@ def lib():
         L.vxo_morton3d.restype = C.c_uint64
         L.vxo_octree_build.argtypes = [fp, C.c_size_t, ip, C.c_size_t, C.c_float, C.c_uint64, C.c_int]
         L.vxo_octree_build.restype = C.c_void_p
+        L.vxo_octree_from_sorted_items.argtypes = [u64p, C.c_uint64, C.c_uint32, C.c_uint64]
+        L.vxo_octree_from_sorted_items.restype = C.c_void_p
         for name in ("vxo_octree_num_items", "vxo_octree_num_nodes", "vxo_octree_bytes"):
             getattr(L, name).argtypes = [C.c_void_p]
             getattr(L, name).restype = C.c_uint64
@@ -207,6 +209,33 @@ def octree(verts, idx, vs, max_items=16, threads=1):
                     root_min=mn, root_max=mx)
     finally:
         lib().vxo_octree_free(h)
+
+
+def octree_nodes_from_sorted_items(items, bits, max_items=16):
+    """Octree::buildTree on an already sorted item list (see vxo_octree_from_sorted_items) -> node array."""
+    it = np.ascontiguousarray(items, dtype=np.uint64)
+    h = lib().vxo_octree_from_sorted_items(_u64(it), it.size, int(bits), int(max_items))
+    if not h:
+        raise RuntimeError("octree_nodes_from_sorted_items: more than 21 bits per axis or 2^32 items")
+    try:
+        nn = int(lib().vxo_octree_num_nodes(h))
+        nodes = np.zeros(max(nn, 1), dtype=NODE)
+        lib().vxo_octree_copy_nodes(h, nodes.ctypes.data_as(C.POINTER(C.c_uint32)))
+        return nodes[:nn]
+    finally:
+        lib().vxo_octree_free(h)
+
+
+def morton3d_np(x, y, z):
+    """Octree::morton3D (octTree.hpp:211-218, incl. its low-16-bit quirk) on arrays: must equal morton3d element by element."""
+    def part(v):
+        v = v.astype(np.uint64) & np.uint64(0xFFFF)
+        v = (v | (v << np.uint64(16))) & np.uint64(0x0000FF0000FF)
+        v = (v | (v << np.uint64(8))) & np.uint64(0x00F00F00F00F)
+        v = (v | (v << np.uint64(4))) & np.uint64(0x0C30C30C30C3)
+        v = (v | (v << np.uint64(2))) & np.uint64(0x249249249249)
+        return v
+    return part(np.asarray(x)) | (part(np.asarray(y)) << np.uint64(1)) | (part(np.asarray(z)) << np.uint64(2))
 
 
 def hit_aabb(box, o, d):

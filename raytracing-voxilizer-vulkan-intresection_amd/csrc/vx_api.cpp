@@ -335,8 +335,15 @@ struct vx_octree {
     uint64_t max_items = 16;
     uint64_t nitems = 0;
     DevBuf items;  // sorted Morton codes
-    vx_octree_node* dnodes = nullptr;  // pre-order node array (device, hipMalloc)
+    vx_octree_node* dnodes = nullptr;  // pre-order node array (device): in `nodebuf` (pooled) or hipMalloc'ed (level-by-level build)
+    DevBuf nodebuf;
     uint64_t nnodes = 0;
+    void free_nodes(bool in_flight)
+    {
+        if (nodebuf.p) nodebuf.release(in_flight);
+        else if (dnodes) (void)hipFree(dnodes);
+        dnodes = nullptr;
+    }
 };
 
 namespace {
@@ -1490,17 +1497,17 @@ vx_status vx_octree_build(const vx_mesh* mesh_c, float vs, uint64_t max_items, v
     o->stream = s;
     o->vs = vs;
     o->max_items = max_items;
-    o->items.dev = o->device;
-    o->items.stream = s;
-    DevBuf small, recs, units, ubase, btri, scantmp, umask, hbase, unsorted, sorttmp;
-    for (DevBuf* b : {&small, &recs, &units, &ubase, &btri, &scantmp, &umask, &hbase, &unsorted, &sorttmp}) { b->dev = o->device; b->stream = s; }
+    o->items.dev = o->nodebuf.dev = o->device;
+    o->items.stream = o->nodebuf.stream = s;
+    DevBuf small, recs, units, ubase, btri, scantmp, umask, hbase, unsorted, sorttmp, ncount, nbase;
+    for (DevBuf* b : {&small, &recs, &units, &ubase, &btri, &scantmp, &umask, &hbase, &unsorted, &sorttmp, &ncount, &nbase}) { b->dev = o->device; b->stream = s; }
     Mail* mail = nullptr;
     auto cleanup = [&]() {
-        for (DevBuf* b : {&small, &recs, &units, &ubase, &btri, &scantmp, &umask, &hbase, &unsorted, &sorttmp}) b->release();
+        for (DevBuf* b : {&small, &recs, &units, &ubase, &btri, &scantmp, &umask, &hbase, &unsorted, &sorttmp, &ncount, &nbase}) b->release();
         if (mail) (void)hipHostFree(mail);
         mail = nullptr;
     };
-    auto bail = [&](vx_status st) { cleanup(); o->items.release(); if (o->dnodes) (void)hipFree(o->dnodes); delete o; return st; };
+    auto bail = [&](vx_status st) { cleanup(); o->items.release(); o->free_nodes(true); delete o; return st; };
 #define OCT_HIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return bail(fail(VX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__))); } while (0)
 #define OCT_TRY(expr) do { vx_status s__ = (expr); if (s__ != VX_OK) return bail(s__); } while (0)
     OCT_HIP(ensure_small(small));
@@ -1544,8 +1551,28 @@ vx_status vx_octree_build(const vx_mesh* mesh_c, float vs, uint64_t max_items, v
         OCT_HIP(sorttmp.ensure(tb));
         vx::launch_sort_u64(unsorted.as<uint64_t>(), o->items.as<uint64_t>(), hits, o->bits ? (int)(3 * o->bits) : 1, sorttmp.p, tb, s);  // octTree.hpp:363
     }
-    // node array: breadth-first expansion + pre-order renumbering on the device (octTree.hpp:319-358, :371)
-    OCT_HIP(vx::build_octree_nodes(o->items.as<uint64_t>(), (uint32_t)hits, o->bits, max_items, &o->dnodes, &o->nnodes, s));
+    // node array (octTree.hpp:319-358, :371)
+    if (hits && max_items <= vx::kOctDirectMaxItems) {
+        // direct form (vx_octree.hip): nodes starting at every item position -> scan -> start / count / links; one wait for the node count
+        const uint32_t ni = (uint32_t)hits;
+        OCT_HIP(ncount.ensure((size_t)ni + 16));
+        OCT_HIP(nbase.ensure(((size_t)ni + 2) * 4));
+        OCT_HIP(ensure_scan_tmp(scantmp, vx::scan_tmp_bytes(ni), s));
+        vx::launch_oct_depths(o->items.as<uint64_t>(), ni, o->bits, (uint32_t)max_items, ncount.as<uint8_t>(), s);
+        vx::launch_scan_u8(ncount.as<uint8_t>(), nbase.as<uint32_t>(), ni, scantmp.p, &mail->occupied, s);
+        OCT_HIP(hipStreamSynchronize(s));
+        const unsigned long long nn = mail->occupied & kMailValue;
+        if (nn == 0 || nn >= 0xFFFFFFFFull) return bail(fail(VX_ERR_CAPACITY, "more than 2^32 octree nodes"));
+        OCT_HIP(o->nodebuf.ensure((size_t)nn * sizeof(vx_octree_node)));
+        o->dnodes = o->nodebuf.as<vx_octree_node>();
+        OCT_HIP(hipMemsetAsync(o->dnodes, 0xFF, (size_t)nn * sizeof(vx_octree_node), s));  // children = 0xFFFFFFFF (none)
+        vx::launch_oct_nodes(o->items.as<uint64_t>(), ni, o->bits, nbase.as<uint32_t>(), o->dnodes, s);
+        OCT_HIP(hipStreamSynchronize(s));
+        o->nnodes = nn;
+    } else {
+        // level by level: breadth-first expansion + pre-order renumbering (any max_items; also the empty item list's lone root)
+        OCT_HIP(vx::build_octree_nodes(o->items.as<uint64_t>(), (uint32_t)hits, o->bits, max_items, &o->dnodes, &o->nnodes, s));
+    }
     cleanup();
 #undef OCT_HIP
 #undef OCT_TRY
@@ -1627,7 +1654,7 @@ void vx_octree_free(vx_octree* o)
         DeviceGuard dg(o->device);
         (void)hipStreamSynchronize(o->stream);
         o->items.release(/*in_flight=*/false);
-        if (o->dnodes) (void)hipFree(o->dnodes);
+        o->free_nodes(/*in_flight=*/false);
     }
     delete o;
 }

@@ -70,6 +70,9 @@ bool launch_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, bool popcoun
                      unsigned long long* total64, hipStream_t s, bool tmp_is_zero = false, unsigned long long total_tag = 0,
                      uint32_t* sel1024 = nullptr /*optional (single-pass kernel only, values <= 1024): sel1024[c] = the element whose range holds c * 1024*/);
 
+void launch_scan_u8(const uint8_t* in, uint32_t* out, uint64_t n, void* tmp /*scan_tmp_bytes(n), all zero*/, unsigned long long* total64, hipStream_t s,
+                    unsigned long long total_tag = 0);
+
 // K2: triangle/voxel overlap over all work units; ORs hits into `words` (only words in [wb,we)), optionally
 // stores each unit's 32-bit hit mask (unit_mask) for the ordered emitters; adds the hit count to *set_calls.
 // block_tri (optional): per 256-unit block the triangle of its first unit (launch_unit_blocks), enables LDS staging.
@@ -143,7 +146,15 @@ void launch_set_bit(uint32_t* words, uint64_t idx, hipStream_t s);
 size_t sort_tmp_bytes(uint64_t n);
 void launch_sort_u64(uint64_t* keys_in, uint64_t* keys_out, uint64_t n, int bits, void* tmp, size_t tmp_bytes, hipStream_t s);
 
-// Octree node array (pre-order, octTree.hpp:319-358) built on the device from the sorted items; *nodes_out is hipMalloc'ed.
+// Octree node array, direct form (max_items <= kOctDirectMaxItems): per item position the number of nodes that START there
+// (launch_oct_depths, bytes), an exclusive scan of those = the pre-order index of the first of them, then start / count / child links
+// (launch_oct_nodes) into a node array the caller has filled with 0xFF bytes.
+constexpr uint64_t kOctDirectMaxItems = 64;
+void launch_oct_depths(const uint64_t* items, uint32_t nitems, uint32_t bits, uint32_t max_items, uint8_t* ncount, hipStream_t s);
+void launch_oct_nodes(const uint64_t* items, uint32_t nitems, uint32_t bits, const uint32_t* base, vx_octree_node* nodes, hipStream_t s);
+
+// Octree node array (pre-order, octTree.hpp:319-358) built on the device from the sorted items, level by level (any max_items);
+// *nodes_out is hipMalloc'ed.
 hipError_t build_octree_nodes(const uint64_t* items, uint32_t nitems, uint32_t max_depth, uint64_t max_items, vx_octree_node** nodes_out,
                               uint64_t* nnodes_out, hipStream_t s);
 

@@ -296,7 +296,8 @@ constexpr unsigned long long kScanFlagA = 1ull << 62, kScanFlagP = 2ull << 62, k
 #endif
 constexpr int kOneBlock = VX_SCAN_BLOCK, kOneItems = VX_SCAN_ITEMS, kOneTile = kOneBlock * kOneItems;
 
-template <bool POPC>
+// MODE 0: the uint32 values themselves, 1: their popcounts, 2: `in` is an array of BYTES (n of them), sixteen per 16-byte load
+template <int MODE>
 __global__ __launch_bounds__(kOneBlock) void k_scan_onepass(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t n,
                                                            unsigned long long* status /*[0]: ticket, [1]: finished tiles, [2 + tile]: state*/, uint32_t ntiles,
                                                            unsigned long long* total, unsigned long long total_tag /*OR-ed into *total: bits 48..63*/,
@@ -312,7 +313,20 @@ __global__ __launch_bounds__(kOneBlock) void k_scan_onepass(const uint32_t* __re
     const uint64_t base = (uint64_t)tile * kOneTile + (uint64_t)threadIdx.x * kOneItems;
     unsigned v[kOneItems];
     const bool full = base + kOneItems <= n;
-    if (full) {
+    constexpr bool POPC = MODE == 1;
+    if (MODE == 2) {
+        static_assert(kOneItems == 16, "one 16-byte load per thread");
+        const uint8_t* inb = reinterpret_cast<const uint8_t*>(in);
+        if (full) {
+            const uint4 a = *reinterpret_cast<const uint4*>(inb + base);
+            const uint32_t w4[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int j = 0; j < kOneItems; ++j) v[j] = (w4[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+        } else {
+#pragma unroll
+            for (int j = 0; j < kOneItems; ++j) v[j] = base + j < n ? (unsigned)inb[base + j] : 0u;
+        }
+    } else if (full) {
 #pragma unroll
         for (int q = 0; q < kOneItems / 4; ++q) {
             const uint4 a = *reinterpret_cast<const uint4*>(in + base + 4 * q);
@@ -426,8 +440,8 @@ bool launch_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, bool popcoun
     if (!three_pass && aligned) {
         const uint32_t ntiles = (uint32_t)(((n + 1) + kOneTile - 1) / kOneTile);
         if (!tmp_is_zero) (void)hipMemsetAsync(status, 0, (size_t)(ntiles + 2) * sizeof(unsigned long long), s);
-        if (popcount_input) VX_KL(k_scan_onepass<true>, dim3(ntiles), dim3(kOneBlock), 0, s, in, out, n, status, ntiles, total64, total_tag, sel1024);
-        else VX_KL(k_scan_onepass<false>, dim3(ntiles), dim3(kOneBlock), 0, s, in, out, n, status, ntiles, total64, total_tag, sel1024);
+        if (popcount_input) VX_KL(k_scan_onepass<1>, dim3(ntiles), dim3(kOneBlock), 0, s, in, out, n, status, ntiles, total64, total_tag, sel1024);
+        else VX_KL(k_scan_onepass<0>, dim3(ntiles), dim3(kOneBlock), 0, s, in, out, n, status, ntiles, total64, total_tag, sel1024);
         return true;
     }
     unsigned long long* sums = status;
@@ -442,6 +456,14 @@ bool launch_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, bool popcoun
     }
     if (tmp_is_zero) (void)hipMemsetAsync(status, 0, scan_tmp_bytes(n), s);  // keep the caller's "zero between scans" contract
     return false;  // (*total64 carries no tag)
+}
+
+// exclusive scan of n BYTES into out[0..n] (uint32); single-pass kernel only (in and out 16-byte aligned, tmp all zero before and after)
+void launch_scan_u8(const uint8_t* in, uint32_t* out, uint64_t n, void* tmp, unsigned long long* total64, hipStream_t s, unsigned long long total_tag)
+{
+    const uint32_t ntiles = (uint32_t)(((n + 1) + kOneTile - 1) / kOneTile);
+    VX_KL(k_scan_onepass<2>, dim3(ntiles), dim3(kOneBlock), 0, s, reinterpret_cast<const uint32_t*>(in), out, n, (unsigned long long*)tmp, ntiles, total64, total_tag,
+          (uint32_t*)nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------------------

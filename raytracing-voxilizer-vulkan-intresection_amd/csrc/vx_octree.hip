@@ -2,7 +2,24 @@
 // (replaces Octree::buildNodeRecursive, octTree.hpp:319-358).
 //
 // The reference recurses depth-first: node = {children[8], start, count}, leaf iff depth >= maxDepth || count <= maxItems,
-// child octant = (code >> 3*(maxDepth-1-depth)) & 7, nodes appended in PRE-ORDER.  Here the tree is expanded breadth-first,
+// child octant = (code >> 3*(maxDepth-1-depth)) & 7, nodes appended in PRE-ORDER.
+//
+// DIRECT FORM (maxItems <= 64, the reference's default is 16) -- no recursion, no levels, one host wait for the node count:
+//   * a node is a maximal run of items sharing their first d octal digits (its depth); in pre-order a node precedes exactly the
+//     nodes with a larger (start, depth) pair, so the nodes that START at item position i are consecutive in the array, ordered by
+//     depth: depths d0(i) .. d1(i);
+//   * d0(i) = lcp(item[i-1], item[i]) + 1 (0 for i = 0): a run of every deeper depth begins where the common prefix ends;
+//   * a node of depth d exists iff its parent splits, i.e. iff the depth-(d-1) run holding i has more than maxItems items.  Runs
+//     are contiguous, so that run has > m items iff some window item[j], item[j+m] with j <= i <= j+m shares d-1 digits:
+//     D(i) = max over j in [i-m, i] of lcp(item[j], item[j+m]) is the deepest splitting depth over i, d1(i) = min(maxDepth, D(i)+1);
+//   * k_oct_depths writes n(i) = d1 - d0 + 1 (or 0) per position, an exclusive scan gives the pre-order index of (i, d0(i));
+//   * k_oct_nodes: thread i writes start / count of its nodes (the end of a run by a galloping search from i) and links each node
+//     into its parent -- the previous node of the same thread, or for the shallowest one the node that owns the run of depth
+//     d0-1 around i (start found by a backward galloping search).  The node array is pre-filled with 0xFF (children = none).
+// Traffic: items twice, one byte and one uint32 per item, 40 B per node -- against a sort of (start, depth) keys and two
+// passes of seven binary searches per node and level in the level-by-level form below (kept for maxItems > 64).
+//
+// LEVEL-BY-LEVEL FORM: the tree is expanded breadth-first,
 // one level per pass (every node of a level splits its item range with seven binary searches), and the pre-order numbering
 // is recovered afterwards: in pre-order a node precedes exactly the nodes with a larger (start, depth) pair -- a node's
 // subtree is a contiguous item range, children are visited in ascending start, and nested nodes with equal start are
@@ -22,6 +39,115 @@ namespace vx {
     } while (0)
 
 namespace {
+
+// number of leading octal digits (of `bits` per code) two codes share
+__device__ __forceinline__ int lcp_digits(uint64_t a, uint64_t b, int bits)
+{
+    if (a == b) return bits;
+    const int hb = 63 - __clzll((long long)(a ^ b));  // highest differing bit
+    const int d = (3 * bits - 1 - hb) / 3;            // digits above it
+    return d < 0 ? 0 : d;
+}
+
+constexpr uint32_t kDepthTile = 1024;  // item positions per workgroup
+constexpr uint32_t kDepthHalo = (uint32_t)kOctDirectMaxItems;
+
+__global__ __launch_bounds__(256) void k_oct_depths(const uint64_t* __restrict__ items, uint32_t n, int bits, uint32_t m, uint8_t* __restrict__ ncount)
+{
+    __shared__ uint64_t codes[kDepthTile + 2 * kDepthHalo + 2];  // codes[c] = item[t0 - (m + 1) + c]
+    __shared__ int8_t L[kDepthTile + kDepthHalo];                // L[c] = lcp(item[j], item[j + m]) for j = t0 - m + c (-1: no such window)
+    const int64_t t0 = (int64_t)blockIdx.x * kDepthTile;
+    const int64_t lo = t0 - (int64_t)(m + 1);
+    const uint32_t ncodes = kDepthTile + 2u * m + 1u;
+    for (uint32_t c = threadIdx.x; c < ncodes; c += 256u) {
+        const int64_t j = lo + c;
+        codes[c] = (j >= 0 && j < (int64_t)n) ? items[j] : 0ull;
+    }
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < kDepthTile + m; c += 256u) {
+        const int64_t j = t0 - (int64_t)m + c;
+        const bool valid = j >= 0 && j + (int64_t)m < (int64_t)n;
+        L[c] = valid ? (int8_t)lcp_digits(codes[c + 1u], codes[c + 1u + m], bits) : (int8_t)-1;
+    }
+    __syncthreads();
+    const uint32_t k0 = threadIdx.x * 4u;
+    uint32_t packed = 0u;
+#pragma unroll
+    for (uint32_t e = 0; e < 4u; ++e) {
+        const uint32_t k = k0 + e;
+        const int64_t i = t0 + k;
+        uint32_t nn = 0u;
+        if (i < (int64_t)n) {
+            int D = -1;
+            for (uint32_t q = 0; q <= m; ++q) { const int l = (int)L[k + q]; D = l > D ? l : D; }
+            const int d0 = i == 0 ? 0 : lcp_digits(codes[k + m], codes[k + m + 1u], bits) + 1;
+            const int d1 = D + 1 < bits ? D + 1 : bits;
+            nn = d1 >= d0 ? (uint32_t)(d1 - d0 + 1) : 0u;
+        }
+        packed |= nn << (8u * e);
+    }
+    const int64_t i0 = t0 + k0;
+    if (i0 + 3 < (int64_t)n) *reinterpret_cast<uint32_t*>(ncount + i0) = packed;  // (t0 and k0 are multiples of four)
+    else
+        for (uint32_t e = 0; e < 4u; ++e)
+            if (i0 + e < (int64_t)n) ncount[i0 + e] = (uint8_t)(packed >> (8u * e));
+}
+
+__global__ __launch_bounds__(256) void k_oct_nodes(const uint64_t* __restrict__ items, uint32_t n, int bits, const uint32_t* __restrict__ base,
+                                                   vx_octree_node* __restrict__ nodes)
+{
+    const uint64_t gi = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (gi >= n) return;
+    const uint32_t i = (uint32_t)gi;
+    const uint32_t b0 = base[i], nn = base[i + 1u] - b0;
+    if (!nn) return;
+    const uint64_t code = items[i];
+    const int d0 = i == 0u ? 0 : lcp_digits(items[i - 1u], code, bits) + 1;
+    uint32_t end_prev = n;
+    for (uint32_t q = 0; q < nn; ++q) {
+        const int d = d0 + (int)q;
+        const int shift = 3 * (bits - d);
+        const uint64_t pref = shift < 64 ? code >> shift : 0ull;
+        // end of the depth-d run that starts at i: inside the end of the shallower run
+        uint32_t lo = i, hi = end_prev;  // item[lo] is in the run; the first item outside lies in (lo, hi]
+        for (uint64_t step = 1;; step <<= 1) {
+            const uint64_t p = (uint64_t)i + step;
+            if (p >= hi) break;
+            if ((shift < 64 ? items[p] >> shift : 0ull) == pref) lo = (uint32_t)p; else { hi = (uint32_t)p; break; }
+        }
+        while (hi - lo > 1u) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if ((shift < 64 ? items[mid] >> shift : 0ull) == pref) lo = mid; else hi = mid;
+        }
+        const uint32_t id = b0 + q;
+        nodes[id].start = i;          // octTree.hpp:325-327
+        nodes[id].count = hi - i;
+        end_prev = hi;
+        if (d > 0) {
+            uint32_t parent;
+            if (q > 0u) parent = id - 1u;
+            else {
+                // the node of depth d - 1 around i: its run starts at the smallest p whose first d - 1 digits equal i's
+                const int sp = 3 * (bits - (d - 1));
+                const uint64_t pp = sp < 64 ? code >> sp : 0ull;
+                uint32_t in = i;        // known inside
+                int64_t out = -1;       // known outside (or -1)
+                for (uint64_t step = 1;; step <<= 1) {
+                    if (step > i) break;  // (i - step < 0)
+                    const uint32_t p = i - (uint32_t)step;
+                    if ((sp < 64 ? items[p] >> sp : 0ull) == pp) in = p; else { out = (int64_t)p; break; }
+                }
+                while ((int64_t)in - out > 1) {
+                    const uint32_t mid = (uint32_t)(out + (((int64_t)in - out) >> 1));
+                    if ((sp < 64 ? items[mid] >> sp : 0ull) == pp) in = mid; else out = (int64_t)mid;
+                }
+                const int d0p = in == 0u ? 0 : lcp_digits(items[in - 1u], items[in], bits) + 1;
+                parent = base[in] + (uint32_t)((d - 1) - d0p);
+            }
+            nodes[parent].children[(uint32_t)(code >> shift) & 7u] = id;  // octTree.hpp:343,351
+        }
+    }
+}
 
 // first position in [lo, hi) whose octant at `shift` is >= c
 __device__ __forceinline__ uint32_t octant_lower_bound(const uint64_t* __restrict__ items, uint32_t lo, uint32_t hi, uint32_t shift, uint32_t c)
@@ -142,6 +268,18 @@ hipError_t grow(Buf& b, size_t keep_bytes, size_t need_bytes, hipStream_t s)
 }
 
 }  // namespace
+
+void launch_oct_depths(const uint64_t* items, uint32_t nitems, uint32_t bits, uint32_t max_items, uint8_t* ncount, hipStream_t s)
+{
+    if (!nitems) return;
+    VX_KL(k_oct_depths, dim3((nitems + kDepthTile - 1) / kDepthTile), dim3(256), 0, s, items, nitems, (int)bits, max_items, ncount);
+}
+
+void launch_oct_nodes(const uint64_t* items, uint32_t nitems, uint32_t bits, const uint32_t* base, vx_octree_node* nodes, hipStream_t s)
+{
+    if (!nitems) return;
+    VX_KL(k_oct_nodes, dim3((nitems + 255) / 256), dim3(256), 0, s, items, nitems, (int)bits, base, nodes);
+}
 
 // Builds the node array on the device.  items: sorted Morton codes (device).  On success *nodes_out is a hipMalloc'ed array
 // of *nnodes_out nodes (the caller frees it with hipFree).

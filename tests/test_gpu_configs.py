@@ -217,8 +217,9 @@ def formula_t(oa, prim, rays):
 # ---------------------------------------------------------------------------------------------- BASELINE configs[2]: the bench workload
 def test_c3_bench_workload_ray_parity(gpu):
     """atrium262k at exactly 512^3 with bench.py's own ray batch (1M random rays, seed 2): the whole batch is traced as the
-    bench traces it; 3000 sampled rays of it plus 3000 rays starting INSIDE the hall are compared with the brute force over
-    all occupied boxes, and every hit of the batch must be the rint formula of its reported box."""
+    bench traces it and compared in full (t and primitive bit-equal) with the oracle's grid walk; 3000 sampled rays of it plus
+    3000 rays starting INSIDE the hall are compared with the brute force over all occupied boxes (the definition), and every
+    hit of the batch must be the rint formula of its reported box."""
     v, t = vx_scenes.scene("atrium262k")
     vs = np.float32((v.max(0) - v.min(0)).max() / 512)
     mesh = gpu.Mesh.from_arrays(v, t)
@@ -231,6 +232,10 @@ def test_c3_bench_workload_ray_parity(gpu):
     sel = np.random.default_rng(61).choice(len(rays), 3000, replace=False)
     ot, op = oracle.trace_brute(oa, rays[sel], threads=NCORES)
     assert np.array_equal(tt[sel], ot) and np.array_equal(pp[sel], op)
+    # 100 % of the batch against the oracle's grid-walking tracer (CPU-proven equal to the brute force; re-checked here on the sample)
+    wt, wp = oracle.trace_walk(ow, gi, vs, rays, threads=NCORES)
+    assert np.array_equal(wt[sel], ot) and np.array_equal(wp[sel], op)
+    assert np.array_equal(tt, wt) and np.array_equal(pp, wp)
     h = np.flatnonzero(tt > 0)
     assert len(h) == nh and np.all(pp[tt <= 0] == 0xFFFFFFFF)
     assert np.array_equal(formula_t(oa, pp[h], rays[h]), tt[h])
@@ -266,10 +271,12 @@ def test_c4_atrium_1024_rays(gpu):
 # ---------------------------------------------------------------------------------------------- BASELINE configs[4]: 10M tris, 2048^3
 def test_c5_soup_10m_2048_octree_and_primary_rays(gpu):
     """Synthetic 10M-triangle soup at 2048^3: VoxelGridBool occupancy, the Octree (sparse) path and 100M coherent primary rays
-    (a 10000 x 10000 image from the reference camera model, raytrace.rgen:41-47, aimed so that most rays hit).  The oracle
-    cannot voxelize 10M triangles in test time, so the occupancy is checked on a sampled triangle subset and through
-    size-independent properties; the rays ARE checked against the definition: brute force over all ~75M boxes on sampled
-    rays (a skipped closer box would show), plus the formula property on a large sample."""
+    (a 10000 x 10000 image from the reference camera model, raytrace.rgen:41-47, aimed so that most rays hit).  Occupancy and
+    octree are compared IN FULL with the threaded oracle: all 2^28 bitmask words, the setVoxel call count, all ~75M sorted
+    Morton items (the oracle's hit stream, Morton-coded and sorted with numpy -- sorting uint64 keys has one answer -- instead of
+    the C restatement's qsort) and all ~15M 40-byte nodes (Octree::buildNodeRecursive restated, run on that sorted list).
+    The rays are checked against the definition: brute force over all ~75M boxes on sampled rays (a skipped closer box would
+    show), the oracle's grid walk on a 2M-ray sample, plus the formula property on a large sample."""
     import torch
     NT, G = 10_000_000, 2048
     v, t = vx_scenes.soup(NT, seed=4, edge=1.5 / G)
@@ -284,31 +291,36 @@ def test_c5_soup_10m_2048_octree_and_primary_rays(gpu):
     assert d["dim"] == gi["dim"] and int(np.prod(d["dim"])) > 2 ** 32
     words = g.bitmask()
     assert int(np.bitwise_count(words).sum()) == d["occupied"]
-    # occupancy: the oracle's hits of a random 20 000-triangle subset are all set, and a subset-only GPU build equals the oracle's
-    sel = np.sort(np.random.default_rng(5).choice(NT, 20000, replace=False))
-    h = oracle.hits(v, t[sel], vs, threads=min(NCORES, 64))
+    # ---- occupancy in full: the oracle's hit stream of ALL triangles (threaded driver, SAT a7 as the Octree uses it; the two SAT
+    # variants give the same verdicts, I1) -> bitmask words and call count
+    nthr = min(NCORES, 64)
+    h = oracle.hits(v, t, vs, threads=nthr, sat=0)
+    assert len(h) == d["set_calls"]
     X, Y = np.uint64(d["dim"][0]), np.uint64(d["dim"][1])
     idx = h[:, 0].astype(np.uint64) + X * (h[:, 1].astype(np.uint64) + Y * h[:, 2].astype(np.uint64))
-    assert np.all((words[(idx >> np.uint64(5)).astype(np.int64)] >> (idx & np.uint64(31)).astype(np.uint32)) & 1)
-    sub = torch.from_numpy(np.ascontiguousarray(t[sel])).to(dev)
-    msub = gpu.Mesh.from_device(dv.data_ptr(), len(v), sub.data_ptr(), len(sel), keep=(dv, sub))
-    gsub = gpu.Grid.voxelize(msub, vs, gpu.GRID_BOOL)
-    wsub = gsub.bitmask()
-    exp = np.zeros_like(wsub)
-    np.bitwise_or.at(exp, (idx >> np.uint64(5)).astype(np.int64), (np.uint32(1) << (idx & np.uint64(31)).astype(np.uint32)))
-    assert np.array_equal(wsub, exp) and gsub.describe()["set_calls"] == len(h)
-    del gsub, wsub, exp
-    # octree: sorted Morton items with duplicates, one per setVoxel call; unique(items) == occupied; memory formula
+    exp = np.zeros_like(words)
+    # (bitwise_or.at is slow on 75M entries: sort the voxel indices, OR the bits of equal words with reduceat)
+    idx.sort()
+    wi = (idx >> np.uint64(5)).astype(np.int64)
+    bits = np.uint32(1) << (idx & np.uint64(31)).astype(np.uint32)
+    first = np.flatnonzero(np.r_[True, wi[1:] != wi[:-1]])
+    exp[wi[first]] = np.bitwise_or.reduceat(bits, first)
+    assert np.array_equal(words, exp), "occupancy bitmask differs from the oracle's (all 10M triangles)"
+    del exp, wi, bits, first, idx
+    # ---- octree in full: items and nodes byte for byte
     o = gpu.Octree(mesh, vs)
     assert o.num_items == d["set_calls"]
     items = o.items()
-    assert np.all(items[:-1] <= items[1:])
+    oitems = oracle.morton3d_np(h[:, 0], h[:, 1], h[:, 2])
+    del h
+    oitems.sort()
+    assert np.array_equal(items, oitems), "sorted Morton items differ from the oracle's"
     assert int((np.diff(items) != 0).sum()) + 1 == d["occupied"]
     assert o.memory_bytes() == 8 * o.num_items + 40 * o.num_nodes
     nodes = o.nodes()
-    leaf = np.all(nodes["children"] == 0xFFFFFFFF, axis=1)
-    assert int(nodes["count"][leaf].sum()) == o.num_items and nodes["count"][0] == o.num_items      # leaves partition the items
-    del items, nodes
+    onodes = oracle.octree_nodes_from_sorted_items(oitems, int(np.ceil(np.log2(max(d["dim"])))), 16)
+    assert len(nodes) == len(onodes) and nodes.tobytes() == onodes.tobytes(), "octree nodes differ from the oracle's"
+    del items, nodes, oitems, onodes
     # rays: 100M primary rays in one launch
     vi, pi = vx_scenes.camera_matrices(eye=(1.55, 1.25, -0.85), ctr=(0.5, 0.5, 0.5), fov_deg=38.0, aspect=1.0)
     W = H = 10000
@@ -333,6 +345,16 @@ def test_c5_soup_10m_2048_octree_and_primary_rays(gpu):
     assert np.array_equal(te, ot) and np.array_equal(pe, op)
     assert np.array_equal(tt > 0, ot > 0) and np.allclose(tt, ot, rtol=0, atol=1e-5)
     assert (pp == op).mean() > 0.98
+    # a 2M-pixel sample of the image as explicit rays: GPU trace == the oracle's grid walk, bit for bit (the walk == the brute force
+    # on the sample above)
+    pix2 = np.sort(rng.choice(W * H, 2_000_000, replace=False)).astype(np.uint64)
+    rays2 = oracle.primary_rays_pixels(vi, pi, W, H, pix2)
+    t2, p2, _ = g.trace(rays2)
+    wt, wp = oracle.trace_walk(words, gi, vs, rays2, threads=NCORES)
+    assert np.array_equal(t2, wt) and np.array_equal(p2, wp)
+    wts, wps = oracle.trace_walk(words, gi, vs, rays, threads=NCORES)
+    assert np.array_equal(wts, ot) and np.array_equal(wps, op)
+    del rays2, t2, p2, wt, wp
     # formula property on 200 000 hits of the image
     ta = d_t.cpu().numpy()
     hh = np.flatnonzero(ta > 0)

@@ -271,8 +271,9 @@ def test_trace_vs_brute_force(gpu, name, vs):
 
 
 def test_trace_blob_256(gpu):
-    """BASELINE configs[1]: ~70k-triangle closed mesh, 256^3, random rays vs the CPU first-hit t (sampled: the brute
-    force over 290k boxes is the slow side)."""
+    """BASELINE configs[1]: ~70k-triangle closed mesh, 256^3, 1M random rays vs the CPU first-hit t.  ALL rays are compared (t and
+    primitive bit-equal) with the oracle's grid-walking tracer, which tests/test_oracle.py proves equal to the brute force; a
+    3000-ray sample is also compared with the brute force over all ~290k boxes itself (the definition)."""
     v, t = vx_scenes.scene("blob70k")
     vs = np.float32(2.0 / 256)
     g, mesh, gi, oa = check_bool(gpu, v, t, vs)
@@ -281,6 +282,10 @@ def test_trace_blob_256(gpu):
     sel = np.random.default_rng(11).choice(len(rays), 3000, replace=False)
     ot, op = oracle.trace_brute(oa, rays[sel])
     assert np.array_equal(tt[sel], ot) and np.array_equal(pp[sel], op)
+    ow, _, _ = oracle.build_bool(v, t, vs)
+    wt, wp = oracle.trace_walk(ow, gi, vs, rays)
+    assert np.array_equal(wt[sel], ot) and np.array_equal(wp[sel], op)          # the checker against the definition
+    assert np.array_equal(tt, wt) and np.array_equal(pp, wp)                    # 100 % of the batch
     # size-independent property on all 1M rays: the reported t is the rint formula of the reported primitive's own box,
     # and no ray reports a t outside the interval
     h = np.flatnonzero(tt > 0)
