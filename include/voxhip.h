@@ -124,10 +124,11 @@ vx_status vx_mesh_set_materials(vx_mesh* m, const vx_material* materials, size_t
 void vx_mesh_free(vx_mesh* m);
 
 /* ---- voxelize: replaces VoxelBuilder<T,inParaell>::buildVoxelGrid (VoxelBuilder.hpp:338-542) ---------------
- * Limits (the reference has none besides memory): at most 65535 cells per axis (the per-triangle candidate ranges are kept
- * as 16-bit start/count pairs) and 2^37 cells in total; beyond either the call fails with VX_ERR_CAPACITY -- also for
- * vx_octree_build, where the reference itself stops at 2^21 cells per axis with the Morton-bits error (octTree.hpp:583-585;
- * that message is reported as VX_ERR_MORTON_BITS only for axes the 65535 limit lets through, i.e. never today). */
+ * Limits (the reference has none besides memory): at most 2^21 cells per axis -- the bound the reference's own Octree has
+ * (octTree.hpp:583-585); the per-triangle candidate ranges are 16 + 16 bits in the triangle record plus 5 + 5 high bits in an
+ * extension word read only by grids with an axis above 65535 cells -- and 2^37 cells in total.  Beyond either vx_voxelize fails with
+ * VX_ERR_CAPACITY, vx_octree_build with VX_ERR_MORTON_BITS and the reference's message.  Rays (vx_trace*) need every axis to have
+ * at most 65535 cells (VX_ERR_UNSUPPORTED beyond: the walk packs two cell coordinates into one register). */
 vx_status vx_voxelize(const vx_mesh* mesh, float voxel_size, vx_grid_kind kind, const vx_voxelize_opts* opts /*NULL ok*/,
                       vx_grid** out);
 /* same, re-using an existing grid handle's device buffers (steady-state loops; no allocation when sizes repeat) */

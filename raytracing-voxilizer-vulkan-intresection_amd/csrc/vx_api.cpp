@@ -288,7 +288,7 @@ struct vx_grid {
     float bbmin[3] = {0, 0, 0}, bbmax[3] = {0, 0, 0}, bbc[3] = {0, 0, 0};
     uint64_t triangles = 0;
     uint32_t cdim[3] = {0, 0, 0}, c2dim[3] = {0, 0, 0};
-    DevBuf words, cwords, c2words, bricks, idxtmp, ttmp, camera, wprefix, wsel /*word of every 1024th occupied voxel (prefix scan)*/, recs, units, ubase, btri, umask, hbase, scantmp, small, vec, matids, mattmp;
+    DevBuf words, cwords, c2words, bricks, idxtmp, ttmp, camera, wprefix, wsel /*word of every 1024th occupied voxel (prefix scan)*/, recs, ext /*high bits of the candidate ranges*/, units, ubase, btri, umask, hbase, scantmp, small, vec, matids, mattmp;
     std::vector<vx_material> materials;  // m_materials: distinct values in first-use order (VX_VOXELIZE_MATERIALS builds only)
     uint64_t mat_count = 0;              // entries of matids
     bool has_materials = false;
@@ -308,18 +308,18 @@ struct vx_grid {
     void set_dev(int d)
     {
         device = d;
-        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &idxtmp, &ttmp, &camera, &wprefix, &wsel, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec, &matids, &mattmp}) b->dev = d;
+        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &idxtmp, &ttmp, &camera, &wprefix, &wsel, &recs, &ext, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec, &matids, &mattmp}) b->dev = d;
     }
     // the stream this handle queues work on; the pool orders the reuse of released blocks by it
     void set_stream(hipStream_t st)
     {
         if (st != stream && words.p) (void)hipStreamSynchronize(stream);  // work queued on the old stream must not outlive the switch
         stream = st;
-        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &idxtmp, &ttmp, &camera, &wprefix, &wsel, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec, &matids, &mattmp}) b->stream = st;
+        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &idxtmp, &ttmp, &camera, &wprefix, &wsel, &recs, &ext, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec, &matids, &mattmp}) b->stream = st;
     }
     void release_all()
     {
-        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &idxtmp, &ttmp, &camera, &wprefix, &wsel, &recs, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec, &matids, &mattmp}) b->release();
+        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &idxtmp, &ttmp, &camera, &wprefix, &wsel, &recs, &ext, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec, &matids, &mattmp}) b->release();
         if (mail) (void)hipHostFree(mail);
         mail = nullptr;
     }
@@ -405,7 +405,8 @@ struct Extent {
     uint64_t dim[3];
 };
 
-vx_status extent_from_bbox(const float* bb, size_t nv, float vs, Extent* e)
+// morton_error: the caller is the Octree, whose limit of 2^21 cells per axis carries the reference's own message (octTree.hpp:583-585)
+vx_status extent_from_bbox(const float* bb, size_t nv, float vs, Extent* e, bool morton_error = false)
 {
     for (int a = 0; a < 3; ++a) {
         e->mn[a] = bb[a];
@@ -413,18 +414,21 @@ vx_status extent_from_bbox(const float* bb, size_t nv, float vs, Extent* e)
         e->ctr[a] = (bb[a] + bb[3 + a]) * 0.5f;  // VoxelBuilder.hpp:221
         if (nv == 0) { e->dim[a] = 0; continue; }
         const float q = std::ceil((e->mx[a] - e->mn[a]) / vs);  // :347-349
-        if (!(q >= 0.0f) || q > 65535.0f) return fail(VX_ERR_CAPACITY, "grid dimension outside [0, 65535]: voxel size too small for this mesh");
+        if (!(q >= 0.0f) || q > (float)vx::kMaxDim) {
+            if (morton_error && q > (float)vx::kMaxDim) return fail(VX_ERR_MORTON_BITS, "We support up to 21 bits per axis (max 2^21 voxels per dimension)!");
+            return fail(VX_ERR_CAPACITY, "grid dimension outside [0, 2^21]: voxel size too small for this mesh");
+        }
         e->dim[a] = (uint64_t)q;
     }
     return VX_OK;
 }
 
-vx_status compute_extent(const vx_mesh* m, float vs, Small* dsmall, Mail* mail, hipStream_t s, Extent* e)
+vx_status compute_extent(const vx_mesh* m, float vs, Small* dsmall, Mail* mail, hipStream_t s, Extent* e, bool morton_error = false)
 {
     // one kernel: reduction, result into the host mailbox, state restored, per-build setVoxel counter cleared
     vx::launch_bbox(m->dv, m->nv, dsmall->bbox_state, mail->bbox, dsmall->set_calls, s);
     VX_HIP(hipStreamSynchronize(s));
-    return extent_from_bbox(mail->bbox, m->nv, vs, e);
+    return extent_from_bbox(mail->bbox, m->nv, vs, e, morton_error);
 }
 
 vx_status check_voxel_size(float vs)
@@ -447,15 +451,17 @@ constexpr uint64_t kMaxVoxels = 1ull << 37;  // 16 GiB of bitmask
 // The shared front half of buildVoxelGrid for grids and the octree: records, unit counts, unit bases.  In two parts so that
 // the caller can queue work that does not depend on the unit count (clearing the bitmask) before the host waits for it.
 vx_status setup_launch(const vx_mesh* m, const vx::GridParams& g, int sat, uint64_t tb, uint32_t ntri, uint32_t zlo, uint32_t zhi, DevBuf& recs,
-                       DevBuf& units, DevBuf& ubase, DevBuf& scantmp, Mail* mail, hipStream_t s, const vx::DevGrid* dgrid = nullptr,
+                       DevBuf& units, DevBuf& ubase, DevBuf& scantmp, Mail* mail, hipStream_t s, DevBuf& ext, const vx::DevGrid* dgrid = nullptr,
                        unsigned long long mail_tag = 0, bool* tagged = nullptr, void* clear = nullptr, uint64_t clear_bytes = 0,
                        uint64_t shard_wb = 0, uint64_t shard_we = 0)
 {
     VX_HIP(recs.ensure((size_t)ntri * sizeof(vx::TriRec) + 64));
+    VX_HIP(ext.ensure(((size_t)ntri + 1) * 4));  // high bits of the candidate ranges (read only when an axis has more than 65535 cells)
     VX_HIP(units.ensure(((size_t)ntri + 1) * 4));
     VX_HIP(ubase.ensure(((size_t)ntri + 2) * 4));
     VX_HIP(ensure_scan_tmp(scantmp, vx::scan_tmp_bytes(ntri), s));
-    vx::launch_tri_setup(m->dv, m->di, tb, ntri, g, sat, zlo, zhi, recs.as<vx::TriRec>(), units.as<uint32_t>(), s, dgrid, clear, clear_bytes, shard_wb, shard_we);
+    vx::launch_tri_setup(m->dv, m->di, tb, ntri, g, sat, zlo, zhi, recs.as<vx::TriRec>(), units.as<uint32_t>(), s, dgrid, clear, clear_bytes, shard_wb, shard_we,
+                         ext.as<uint32_t>());
     const bool tg = vx::launch_scan_u32(units.as<uint32_t>(), ubase.as<uint32_t>(), ntri, false, scantmp.p, &mail->units, s, true, mail_tag);
     if (tagged) *tagged = tg && mail_tag != 0;
     return VX_OK;
@@ -778,7 +784,7 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
         // the previous build's bitmask is cleared in the same window -- by the record kernel's own threads when there are enough of
         // them (at most 256 bytes each), by a memset behind the block table otherwise
         const bool clear_in_setup = g->words.p && (g->words.cap % 16) == 0 && g->words.cap / 256 <= (size_t)ntri;
-        VX_TRY(setup_launch(mesh, gp, o.sat_variant, tb, ntri, 0, 0, g->recs, g->units, g->ubase, g->scantmp, g->mail, s, &ds->dgrid, mtag, &units_tagged,
+        VX_TRY(setup_launch(mesh, gp, o.sat_variant, tb, ntri, 0, 0, g->recs, g->units, g->ubase, g->scantmp, g->mail, s, g->ext, &ds->dgrid, mtag, &units_tagged,
                             clear_in_setup ? g->words.p : nullptr, clear_in_setup ? g->words.cap : 0, sharded_words ? o.word_begin : 0,
                             sharded_words ? o.word_end : 0));
         if (clear_in_setup) cleared = g->words.cap;
@@ -834,7 +840,7 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
         if (zh > ex.dim[2]) zh = ex.dim[2];
         const uint32_t zhi = (uint32_t)zh;
         // records + unit scan are queued, THEN the bitmask is cleared (it does not depend on the unit count), then the host waits
-        VX_TRY(setup_launch(mesh, g->g, o.sat_variant, tb, ntri, zlo, zhi, g->recs, g->units, g->ubase, g->scantmp, g->mail, s));
+        VX_TRY(setup_launch(mesh, g->g, o.sat_variant, tb, ntri, zlo, zhi, g->recs, g->units, g->ubase, g->scantmp, g->mail, s, g->ext));
         VX_HIP(hipMemsetAsync(g->words.p, 0, mask_bytes, s));
         VX_TRY(setup_finish(ntri, g->ubase, g->btri, g->mail, s, &U));
     }
@@ -844,8 +850,10 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
         VX_HIP(g->umask.ensure((size_t)(U + 1) * 4));
         umask = g->umask.as<uint32_t>();
     }
+    // an axis above 65535 cells: the unit kernels also read the extension words of the candidate ranges
+    const uint32_t* xw = (ex.dim[0] > 65535 || ex.dim[1] > 65535 || ex.dim[2] > 65535) ? g->ext.as<uint32_t>() : nullptr;
     vx::launch_voxelize(g->recs.as<vx::TriRec>(), g->ubase.as<uint32_t>(), g->btri.as<uint32_t>(), ntri, g->g, o.sat_variant,
-                        g->words.as<uint32_t>(), wb, we, umask, ds->set_calls, s);
+                        g->words.as<uint32_t>(), wb, we, umask, ds->set_calls, s, xw);
     g->counts_valid = false;
     bool hits_tagged = false, occ_tagged = false, occ_queued = false;
     if (g->kind == VX_GRID_VEC) {
@@ -874,7 +882,7 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
         g->vec_in_bound = false;
         if (cap_rec)
             vx::launch_emit_units(g->recs.as<vx::TriRec>(), g->ubase.as<uint32_t>(), g->btri.as<uint32_t>(), ntri, g->g, umask,
-                                  g->hbase.as<uint32_t>(), tgt, nullptr, s, to_bound ? g->bound_cap : cap_rec);
+                                  g->hbase.as<uint32_t>(), tgt, nullptr, s, to_bound ? g->bound_cap : cap_rec, xw);
         // The host needs the hit count (and takes the occupied count along).  Both are written by scans that run BEFORE the
         // emission: the host polls the tagged mailbox words and goes on queueing work (the caller's next call: a trace) while
         // the emission still runs; a stream synchronize would wake it ~15 us after the last kernel.  VOXHIP_POLL_MAIL=0, an
@@ -895,7 +903,7 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
         if (hits + 1 > cap_rec) {
             VX_HIP(g->vec.ensure((size_t)(hits + 1) * sizeof(vx_aabb)));
             vx::launch_emit_units(g->recs.as<vx::TriRec>(), g->ubase.as<uint32_t>(), g->btri.as<uint32_t>(), ntri, g->g, umask,
-                                  g->hbase.as<uint32_t>(), g->vec.as<vx_aabb>(), nullptr, s);
+                                  g->hbase.as<uint32_t>(), g->vec.as<vx_aabb>(), nullptr, s, ~0ull, xw);
         }
         g->vec_count = hits;
     }
@@ -914,7 +922,7 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
         int16_t* value_index = reinterpret_cast<int16_t*>(tri_hit + (((size_t)ntri + 63) & ~(size_t)63));
         VX_HIP(hipMemsetAsync(base, 0, (size_t)(tri_hit - base) + ntri, s));
         vx::launch_mat_last(g->recs.as<vx::TriRec>(), g->ubase.as<uint32_t>(), g->btri.as<uint32_t>(), ntri, g->g, umask, g->words.as<uint32_t>(),
-                            g->wprefix.as<uint32_t>(), last_tri, tri_hit, s);
+                            g->wprefix.as<uint32_t>(), last_tri, tri_hit, s, xw);
         std::vector<uint8_t> hit(ntri);
         VX_HIP(hipMemcpyAsync(hit.data(), tri_hit, ntri, hipMemcpyDeviceToHost, s));
         VX_HIP(hipStreamSynchronize(s));
@@ -1092,7 +1100,7 @@ vx_status vx_grid_create(vx_grid_kind kind, uint64_t x, uint64_t y, uint64_t z, 
 {
     if (!out) return fail(VX_ERR_INVALID_ARG, "null argument");
     if (kind != VX_GRID_BOOL && kind != VX_GRID_AABBSTRUCT && kind != VX_GRID_VEC) return fail(VX_ERR_INVALID_ARG, "unknown grid kind");
-    if (x > 65535 || y > 65535 || z > 65535 || x * y * z > kMaxVoxels) return fail(VX_ERR_CAPACITY, "grid too large");
+    if (x > vx::kMaxDim || y > vx::kMaxDim || z > vx::kMaxDim || x * y * z > kMaxVoxels) return fail(VX_ERR_CAPACITY, "grid too large");
     VX_TRY(need_device(g_device));
     vx_grid* g = new vx_grid();
     g->kind = kind;
@@ -1332,6 +1340,8 @@ void vx_grid_free(vx_grid* g)
 // ---- rays -----------------------------------------------------------------------------------------------------
 static vx_status trace_common(vx_grid* g, vx::TraceIO io)
 {
+    if (g->g.dim[0] > 65535u || g->g.dim[1] > 65535u || g->g.dim[2] > 65535u)
+        return fail(VX_ERR_UNSUPPORTED, "rays need a grid of at most 65535 cells per axis (the walk packs two cell coordinates into one register)");
     VX_TRY(ensure_coarse(g));
     const uint32_t* prefix = nullptr;
     void* idx_tmp = nullptr;
@@ -1499,11 +1509,11 @@ vx_status vx_octree_build(const vx_mesh* mesh_c, float vs, uint64_t max_items, v
     o->max_items = max_items;
     o->items.dev = o->nodebuf.dev = o->device;
     o->items.stream = o->nodebuf.stream = s;
-    DevBuf small, recs, units, ubase, btri, scantmp, umask, hbase, unsorted, sorttmp, ncount, nbase;
-    for (DevBuf* b : {&small, &recs, &units, &ubase, &btri, &scantmp, &umask, &hbase, &unsorted, &sorttmp, &ncount, &nbase}) { b->dev = o->device; b->stream = s; }
+    DevBuf small, recs, ext, units, ubase, btri, scantmp, umask, hbase, unsorted, sorttmp, ncount, nbase;
+    for (DevBuf* b : {&small, &recs, &ext, &units, &ubase, &btri, &scantmp, &umask, &hbase, &unsorted, &sorttmp, &ncount, &nbase}) { b->dev = o->device; b->stream = s; }
     Mail* mail = nullptr;
     auto cleanup = [&]() {
-        for (DevBuf* b : {&small, &recs, &units, &ubase, &btri, &scantmp, &umask, &hbase, &unsorted, &sorttmp, &ncount, &nbase}) b->release();
+        for (DevBuf* b : {&small, &recs, &ext, &units, &ubase, &btri, &scantmp, &umask, &hbase, &unsorted, &sorttmp, &ncount, &nbase}) b->release();
         if (mail) (void)hipHostFree(mail);
         mail = nullptr;
     };
@@ -1514,28 +1524,29 @@ vx_status vx_octree_build(const vx_mesh* mesh_c, float vs, uint64_t max_items, v
     Small* ds = small.as<Small>();
     OCT_HIP(mail_alloc(&mail));
     Extent ex;
-    OCT_TRY(compute_extent(mesh, vs, ds, mail, s, &ex));
+    OCT_TRY(compute_extent(mesh, vs, ds, mail, s, &ex, /*morton_error=*/true));
     for (int a = 0; a < 3; ++a) { o->root_min[a] = ex.mn[a]; o->root_max[a] = ex.mx[a]; o->dim[a] = ex.dim[a]; }
     uint64_t maxDim = ex.dim[0] > ex.dim[1] ? ex.dim[0] : ex.dim[1];
     if (ex.dim[2] > maxDim) maxDim = ex.dim[2];
     if (maxDim == 0) { cleanup(); *out = o; return VX_OK; }  // octTree.hpp:571-574
     o->bits = (uint32_t)std::ceil(std::log2((double)maxDim));  // :577-578
     if (o->bits > 21) return bail(fail(VX_ERR_MORTON_BITS, "We support up to 21 bits per axis (max 2^21 voxels per dimension)!"));
-    const float ext = vs * (float)(1u << o->bits);  // :592
-    for (int a = 0; a < 3; ++a) o->root_max[a] = ex.mn[a] + ext;
+    const float root_ext = vs * (float)(1u << o->bits);  // :592
+    for (int a = 0; a < 3; ++a) o->root_max[a] = ex.mn[a] + root_ext;
     const uint32_t ntri = (uint32_t)mesh->nt;
     if (ntri == 0) { cleanup(); *out = o; return VX_OK; }  // :696-699 (returns before buildTree)
     vx::GridParams g;
     fill_params(g, ex.mn, vs, ex.dim);
     uint64_t U = 0;
-    OCT_TRY(setup_launch(mesh, g, /*sat a7: octTree.hpp:762*/ 0, 0, ntri, 0, (uint32_t)ex.dim[2], recs, units, ubase, scantmp, mail, s));
+    OCT_TRY(setup_launch(mesh, g, /*sat a7: octTree.hpp:762*/ 0, 0, ntri, 0, (uint32_t)ex.dim[2], recs, units, ubase, scantmp, mail, s, ext));
+    const uint32_t* xw = (ex.dim[0] > 65535 || ex.dim[1] > 65535 || ex.dim[2] > 65535) ? ext.as<uint32_t>() : nullptr;
     OCT_TRY(setup_finish(ntri, ubase, btri, mail, s, &U));
     unsigned long long hits = 0;
     if (U) {
         OCT_HIP(umask.ensure((size_t)(U + 1) * 4));
         OCT_HIP(hbase.ensure((size_t)(U + 2) * 4));
         OCT_HIP(ensure_scan_tmp(scantmp, vx::scan_tmp_bytes(U), s));
-        vx::launch_voxelize(recs.as<vx::TriRec>(), ubase.as<uint32_t>(), btri.as<uint32_t>(), ntri, g, 0, nullptr, 0, 0, umask.as<uint32_t>(), ds->set_calls, s);
+        vx::launch_voxelize(recs.as<vx::TriRec>(), ubase.as<uint32_t>(), btri.as<uint32_t>(), ntri, g, 0, nullptr, 0, 0, umask.as<uint32_t>(), ds->set_calls, s, xw);
         vx::launch_scan_u32(umask.as<uint32_t>(), hbase.as<uint32_t>(), U, true, scantmp.p, &mail->hits, s, true);
         OCT_HIP(hipStreamSynchronize(s));
         hits = mail->hits & kMailValue;
@@ -1546,7 +1557,7 @@ vx_status vx_octree_build(const vx_mesh* mesh_c, float vs, uint64_t max_items, v
         OCT_HIP(unsorted.ensure((size_t)hits * 8));
         OCT_HIP(o->items.ensure((size_t)hits * 8));
         vx::launch_emit_units(recs.as<vx::TriRec>(), ubase.as<uint32_t>(), btri.as<uint32_t>(), ntri, g, umask.as<uint32_t>(), hbase.as<uint32_t>(),
-                              nullptr, unsorted.as<uint64_t>(), s);
+                              nullptr, unsorted.as<uint64_t>(), s, ~0ull, xw);
         const size_t tb = vx::sort_tmp_bytes(hits);
         OCT_HIP(sorttmp.ensure(tb));
         vx::launch_sort_u64(unsorted.as<uint64_t>(), o->items.as<uint64_t>(), hits, o->bits ? (int)(3 * o->bits) : 1, sorttmp.p, tb, s);  // octTree.hpp:363

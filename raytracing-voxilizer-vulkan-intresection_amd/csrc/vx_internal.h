@@ -17,6 +17,9 @@ struct __attribute__((aligned(16))) TriRec {
 };
 static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
 
+// Cells per axis: the reference's grids are bounded by memory only, its Octree by 21 Morton bits per axis (octTree.hpp:583-585);
+// candidate ranges are kept as 16 + 16 bits per axis in TriRec plus 5 + 5 high bits in a per-triangle extension word.
+constexpr uint32_t kMaxDim = 1u << 21;
 constexpr uint32_t kCoarse = 8;        // cells per brick edge, bricks per block edge (ray traversal structure)
 constexpr uint32_t kCoarseShift = 3;
 constexpr int kScanBlock = 256;
@@ -59,7 +62,8 @@ void launch_bbox(const float* verts, uint64_t nverts, unsigned long long* state7
 void launch_tri_setup(const float* verts, const int32_t* idx, uint64_t tri_begin, uint32_t ntri, const GridParams& g,
                       int sat_variant, uint32_t zlo, uint32_t zhi, TriRec* recs, uint32_t* units, hipStream_t s, const DevGrid* dgrid = nullptr,
                       void* clear = nullptr /*optional: a 16-byte aligned buffer the kernel zeroes beside its own work*/, uint64_t clear_bytes = 0,
-                      uint64_t shard_wb = 0, uint64_t shard_we = 0 /*with dgrid: derive zlo / zhi on the device from the word shard (0, 0: whole grid)*/);
+                      uint64_t shard_wb = 0, uint64_t shard_we = 0 /*with dgrid: derive zlo / zhi on the device from the word shard (0, 0: whole grid)*/,
+                      uint32_t* ext = nullptr /*optional, ntri words: bits 16..20 of the range values, for grids with an axis above 65535 cells*/);
 
 // exclusive scan of n uint32 (or of their popcounts) into out[0..n] (out[n] = total, saturating check via *total64)
 size_t scan_tmp_bytes(uint64_t n);
@@ -79,17 +83,18 @@ void launch_scan_u8(const uint8_t* in, uint32_t* out, uint64_t n, void* tmp /*sc
 void launch_unit_blocks(const uint32_t* unit_base, uint32_t ntri, uint32_t total_units, uint32_t* block_tri, hipStream_t s, uint32_t cap_blocks = 0xFFFFFFFFu);
 void launch_voxelize(const TriRec* recs, const uint32_t* unit_base, const uint32_t* block_tri, uint32_t ntri, const GridParams& g,
                      int sat_variant, uint32_t* words, uint64_t wb, uint64_t we, uint32_t* unit_mask, unsigned long long* set_calls,
-                     hipStream_t s);
+                     hipStream_t s, const uint32_t* ext = nullptr /*k_tri_setup's extension words; null unless an axis has more than 65535 cells*/);
 
 // K3: VoxelGridVec / Octree emitters: one output per set bit of unit_mask, in unit order (== reference order).
 void launch_emit_units(const TriRec* recs, const uint32_t* unit_base, const uint32_t* block_tri, uint32_t ntri, const GridParams& g,
-                       const uint32_t* unit_mask, const uint32_t* hit_base, vx_aabb* aabbs, uint64_t* morton, hipStream_t s, uint64_t cap = ~0ull);
+                       const uint32_t* unit_mask, const uint32_t* hit_base, vx_aabb* aabbs, uint64_t* morton, hipStream_t s, uint64_t cap = ~0ull,
+                       const uint32_t* ext = nullptr);
 
 // Per-voxel material ids (the reference's commented-out addMatrialIfNeeded plumbing): pass 1 = last triangle per occupied voxel
 // (last_tri[rank], zeroed by the caller; may be null for the Vec flavour) + tri_hit[t] = 1 for triangles that set a voxel (zeroed by
 // the caller); pass 2 = triangle -> material value -> index of first use.
 void launch_mat_last(const TriRec* recs, const uint32_t* unit_base, const uint32_t* block_tri, uint32_t ntri, const GridParams& g, const uint32_t* unit_mask,
-                     const uint32_t* words, const uint32_t* word_prefix, uint32_t* last_tri, uint8_t* tri_hit, hipStream_t s);
+                     const uint32_t* words, const uint32_t* word_prefix, uint32_t* last_tri, uint8_t* tri_hit, hipStream_t s, const uint32_t* ext = nullptr);
 void launch_mat_ids(const uint32_t* last_tri, uint64_t n, const int32_t* tri_value, const int16_t* value_index, int16_t* out, hipStream_t s);
 void launch_mat_ids_calls(const TriRec* recs, const uint32_t* unit_base, const uint32_t* block_tri, uint32_t ntri, const uint32_t* unit_mask,
                           const uint32_t* hit_base, const int32_t* tri_value, const int16_t* value_index, int16_t* out, hipStream_t s);

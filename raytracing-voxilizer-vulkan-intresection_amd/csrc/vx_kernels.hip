@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void k_bbox(const float* __restrict__ verts, u
             uint32_t d = 0;
             if (nverts) {
                 const float q = ceilf((mx - val) / vs);
-                d = (q >= 0.0f && q <= 65535.0f) ? (uint32_t)q : 0u;  // out of range: the host reports the error, the device sees an empty grid
+                d = (q >= 0.0f && q <= (float)kMaxDim) ? (uint32_t)q : 0u;  // out of range: the host reports the error, the device sees an empty grid
             }
             dgrid->org[threadIdx.x] = val;
             dgrid->dim[threadIdx.x] = d;
@@ -496,7 +496,8 @@ __global__ __launch_bounds__(256) void k_tri_setup(const float* __restrict__ ver
                                                    uint32_t ntri, GridParams g, float vsize, uint32_t zlo, uint32_t zhi,
                                                    TriRec* __restrict__ recs, uint32_t* __restrict__ units, const DevGrid* __restrict__ dgrid,
                                                    uint4* __restrict__ clear /*optional: 16-byte pieces to zero*/, uint64_t clear_n,
-                                                   uint64_t shard_wb, uint64_t shard_we /*with dgrid: the bitmask words of a sharded build (0, 0: all)*/)
+                                                   uint64_t shard_wb, uint64_t shard_we /*with dgrid: the bitmask words of a sharded build (0, 0: all)*/,
+                                                   uint32_t* __restrict__ ext /*bits 16..20 of the six range values (grids with an axis above 65535 cells)*/)
 {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     // (optional) the build's bitmask is cleared by this kernel's threads, beside their own work: a launch and its gap less
@@ -544,21 +545,26 @@ __global__ __launch_bounds__(256) void k_tri_setup(const float* __restrict__ ver
         const uint64_t uu = (uint64_t)nseg * ny * nz;
         u = uu > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)uu;
     }
-    r.xr = (uint32_t)(nx ? xs : 0) | (nx << 16);
-    r.yr = (uint32_t)(ny ? ys : 0) | (ny << 16);
-    r.zr = (uint32_t)(nz ? zs : 0) | (nz << 16);
+    // start | count << 16 per axis, low 16 bits each; bits 16..20 (cells 65536 .. 2^21 - 1) go to the extension word, which the unit
+    // kernels only read for grids that have such an axis
+    const uint32_t xs_ = nx ? (uint32_t)xs : 0u, ys_ = ny ? (uint32_t)ys : 0u, zs_ = nz ? (uint32_t)zs : 0u;
+    r.xr = (xs_ & 0xFFFFu) | (nx << 16);
+    r.yr = (ys_ & 0xFFFFu) | (ny << 16);
+    r.zr = (zs_ & 0xFFFFu) | (nz << 16);
+    if (ext) ext[t] = (xs_ >> 16) | ((nx >> 16) << 5) | ((ys_ >> 16) << 10) | ((ny >> 16) << 15) | ((zs_ >> 16) << 20) | ((nz >> 16) << 25);
     recs[t] = r;
     units[t] = u;
 }
 
 void launch_tri_setup(const float* verts, const int32_t* idx, uint64_t tri_begin, uint32_t ntri, const GridParams& g, int sat_variant,
-                      uint32_t zlo, uint32_t zhi, TriRec* recs, uint32_t* units, hipStream_t s, const DevGrid* dgrid, void* clear, uint64_t clear_bytes, uint64_t shard_wb, uint64_t shard_we)
+                      uint32_t zlo, uint32_t zhi, TriRec* recs, uint32_t* units, hipStream_t s, const DevGrid* dgrid, void* clear, uint64_t clear_bytes, uint64_t shard_wb, uint64_t shard_we,
+                      uint32_t* ext)
 {
     if (!ntri) return;
     // serial driver: voxelSize = halfVoxelSize.x * 2.0f (VoxelBuilder.hpp:173); threaded driver: vSize = voxelSize (:500)
     const float vsize = sat_variant == 0 ? g.half * 2.0f : g.vs;
     VX_KL(k_tri_setup, dim3((ntri + 255) / 256), dim3(256), 0, s, verts, idx, tri_begin, ntri, g, vsize, zlo, zhi, recs, units, dgrid,
-          reinterpret_cast<uint4*>(clear), clear ? clear_bytes / 16 : 0, shard_wb, shard_we);
+          reinterpret_cast<uint4*>(clear), clear ? clear_bytes / 16 : 0, shard_wb, shard_we, ext);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -582,13 +588,14 @@ __device__ __forceinline__ uint32_t find_tri(const uint32_t* __restrict__ unit_b
     return lo;
 }
 
-__device__ __forceinline__ Unit decode_unit(const TriRec& r, uint32_t tri, uint32_t rel)
+// e: the triangle's extension word (k_tri_setup), 0 for grids without an axis above 65535 cells
+__device__ __forceinline__ Unit decode_unit(const TriRec& r, uint32_t tri, uint32_t rel, uint32_t e = 0u)
 {
     Unit w;
     w.tri = tri;
-    const uint32_t xs = r.xr & 0xFFFFu, nx = r.xr >> 16;
-    const uint32_t ys = r.yr & 0xFFFFu, ny = r.yr >> 16;
-    const uint32_t zs = r.zr & 0xFFFFu;
+    const uint32_t xs = (r.xr & 0xFFFFu) | ((e & 31u) << 16), nx = (r.xr >> 16) | (((e >> 5) & 31u) << 16);
+    const uint32_t ys = (r.yr & 0xFFFFu) | (((e >> 10) & 31u) << 16), ny = (r.yr >> 16) | (((e >> 15) & 31u) << 16);
+    const uint32_t zs = (r.zr & 0xFFFFu) | (((e >> 20) & 31u) << 16);
     const uint32_t seg0 = xs >> 5;
     const uint32_t nseg = ((xs + nx - 1u) >> 5) - seg0 + 1u;
     const uint32_t row = rel / nseg, sx = rel - row * nseg;
@@ -791,7 +798,8 @@ __device__ __forceinline__ void for_each_unit(const TriRec* __restrict__ recs, c
 template <bool EPS, bool STORE_MASK>
 __global__ __launch_bounds__(256) void k_voxelize(const TriRec* __restrict__ recs, const uint32_t* __restrict__ unit_base,
                                                   const uint32_t* __restrict__ block_tri, uint32_t ntri, GridParams g, uint32_t* __restrict__ words,
-                                                  uint64_t wb, uint64_t we, uint32_t* __restrict__ unit_mask, unsigned long long* set_calls)
+                                                  uint64_t wb, uint64_t we, uint32_t* __restrict__ unit_mask, unsigned long long* set_calls,
+                                                  const uint32_t* __restrict__ ext /*null unless the grid has an axis above 65535 cells*/)
 {
     __shared__ UnitStage stage[kStagesPerBlock];
     unsigned hits = 0;
@@ -799,7 +807,7 @@ __global__ __launch_bounds__(256) void k_voxelize(const TriRec* __restrict__ rec
     unsigned sent = 0;  // atomic requests this lane really sent
 #endif
     for_each_unit(recs, unit_base, block_tri, ntri, stage, [&](uint32_t u, uint32_t t, const TriRec& r, uint32_t rel) {
-        const Unit w = decode_unit(r, t, rel);
+        const Unit w = decode_unit(r, t, rel, ext ? ext[t] : 0u);
         const float cy = cell_centre(g.org[1], g.vs, w.y), cz = cell_centre(g.org[2], g.vs, w.z);
         const SatRow row = sat_row_setup<EPS>(r.v, cy, cz, g.half);
         uint32_t mask = 0;
@@ -885,16 +893,16 @@ namespace vx {
 #endif
 
 void launch_voxelize(const TriRec* recs, const uint32_t* unit_base, const uint32_t* block_tri, uint32_t ntri, const GridParams& g, int sat_variant,
-                     uint32_t* words, uint64_t wb, uint64_t we, uint32_t* unit_mask, unsigned long long* set_calls, hipStream_t s)
+                     uint32_t* words, uint64_t wb, uint64_t we, uint32_t* unit_mask, unsigned long long* set_calls, hipStream_t s, const uint32_t* ext)
 {
     if (!ntri) return;
     const dim3 grid(kUnitBlocks), block(256);
     if (sat_variant == 0) {
-        if (unit_mask) VX_KL((k_voxelize<true, true>), grid, block, 0, s, recs, unit_base, block_tri, ntri, g, words, wb, we, unit_mask, set_calls);
-        else VX_KL((k_voxelize<true, false>), grid, block, 0, s, recs, unit_base, block_tri, ntri, g, words, wb, we, unit_mask, set_calls);
+        if (unit_mask) VX_KL((k_voxelize<true, true>), grid, block, 0, s, recs, unit_base, block_tri, ntri, g, words, wb, we, unit_mask, set_calls, ext);
+        else VX_KL((k_voxelize<true, false>), grid, block, 0, s, recs, unit_base, block_tri, ntri, g, words, wb, we, unit_mask, set_calls, ext);
     } else {
-        if (unit_mask) VX_KL((k_voxelize<false, true>), grid, block, 0, s, recs, unit_base, block_tri, ntri, g, words, wb, we, unit_mask, set_calls);
-        else VX_KL((k_voxelize<false, false>), grid, block, 0, s, recs, unit_base, block_tri, ntri, g, words, wb, we, unit_mask, set_calls);
+        if (unit_mask) VX_KL((k_voxelize<false, true>), grid, block, 0, s, recs, unit_base, block_tri, ntri, g, words, wb, we, unit_mask, set_calls, ext);
+        else VX_KL((k_voxelize<false, false>), grid, block, 0, s, recs, unit_base, block_tri, ntri, g, words, wb, we, unit_mask, set_calls, ext);
     }
 }
 
@@ -906,13 +914,14 @@ void launch_voxelize(const TriRec* recs, const uint32_t* unit_base, const uint32
 __global__ __launch_bounds__(256) void k_emit_units(const TriRec* __restrict__ recs, const uint32_t* __restrict__ unit_base,
                                                     const uint32_t* __restrict__ block_tri, uint32_t ntri, GridParams g,
                                                     const uint32_t* __restrict__ unit_mask, const uint32_t* __restrict__ hit_base,
-                                                    vx_aabb* __restrict__ aabbs, uint64_t* __restrict__ morton, uint64_t cap /*records the output can hold*/)
+                                                    vx_aabb* __restrict__ aabbs, uint64_t* __restrict__ morton, uint64_t cap /*records the output can hold*/,
+                                                    const uint32_t* __restrict__ ext)
 {
     __shared__ UnitStage stage[kStagesPerBlock];
     for_each_unit(recs, unit_base, block_tri, ntri, stage, [&](uint32_t u, uint32_t t, const TriRec& r, uint32_t rel) {
         uint32_t mask = unit_mask[u];
         if (!mask) return;
-        const Unit w = decode_unit(r, t, rel);
+        const Unit w = decode_unit(r, t, rel, ext ? ext[t] : 0u);
         uint64_t off = hit_base[u];
         while (mask) {
             const uint32_t b = __ffs(mask) - 1;
@@ -934,12 +943,12 @@ __global__ __launch_bounds__(256) void k_emit_units(const TriRec* __restrict__ r
 }
 
 void launch_emit_units(const TriRec* recs, const uint32_t* unit_base, const uint32_t* block_tri, uint32_t ntri, const GridParams& g,
-                       const uint32_t* unit_mask, const uint32_t* hit_base, vx_aabb* aabbs, uint64_t* morton, hipStream_t s, uint64_t cap)
+                       const uint32_t* unit_mask, const uint32_t* hit_base, vx_aabb* aabbs, uint64_t* morton, hipStream_t s, uint64_t cap, const uint32_t* ext)
 {
     if (!ntri) return;
     // (bound by its stores, not by issue: 4096 workgroups -- several ragged rounds of the six a CU holds -- beat one even set: 45 us
     // with 1536, 41 with 2048, 39 with 4096)
-    VX_KL(k_emit_units, dim3(2u * kMaxBlocks), dim3(256), 0, s, recs, unit_base, block_tri, ntri, g, unit_mask, hit_base, aabbs, morton, cap);
+    VX_KL(k_emit_units, dim3(2u * kMaxBlocks), dim3(256), 0, s, recs, unit_base, block_tri, ntri, g, unit_mask, hit_base, aabbs, morton, cap, ext);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1021,8 +1030,9 @@ __global__ __launch_bounds__(256) void k_emit_bool(const uint32_t* __restrict__ 
                 const uint32_t bit = select_bit(wv, k - before);
                 const uint64_t idx = w * 32ull + bit;  // voxel index -> (x, y, z), voxelgrid.hpp:42-49
                 const uint32_t z = (uint32_t)(idx / XY);
-                const uint32_t rem = (uint32_t)(idx - (uint64_t)z * XY);
-                const uint32_t y = rem / g.dim[0], x = rem - y * g.dim[0];
+                const uint64_t rem = idx - (uint64_t)z * XY;  // (X * Y may exceed 32 bits on a long thin grid)
+                const uint32_t y = (rem >> 32) ? (uint32_t)(rem / g.dim[0]) : (uint32_t)rem / g.dim[0];
+                const uint32_t x = (uint32_t)(rem - (uint64_t)y * g.dim[0]);
                 float bb[6];
                 cell_aabb(g, x, y, z, bb);
                 float2* sp = reinterpret_cast<float2*>(s_rec) + threadIdx.x * 3u;
@@ -1085,7 +1095,7 @@ void launch_emit_morton_aabbs(const uint64_t* items, uint64_t n, const float roo
 __global__ __launch_bounds__(256) void k_mat_last(const TriRec* __restrict__ recs, const uint32_t* __restrict__ unit_base, const uint32_t* __restrict__ block_tri,
                                                   uint32_t ntri, GridParams g, const uint32_t* __restrict__ unit_mask, const uint32_t* __restrict__ words,
                                                   const uint32_t* __restrict__ word_prefix, uint32_t* __restrict__ last_tri /*per occupied voxel, 0 = none yet*/,
-                                                  uint8_t* __restrict__ tri_hit)
+                                                  uint8_t* __restrict__ tri_hit, const uint32_t* __restrict__ ext)
 {
     __shared__ UnitStage stage[kStagesPerBlock];
     for_each_unit(recs, unit_base, block_tri, ntri, stage, [&](uint32_t u, uint32_t t, const TriRec& r, uint32_t rel) {
@@ -1093,7 +1103,7 @@ __global__ __launch_bounds__(256) void k_mat_last(const TriRec* __restrict__ rec
         if (!mask) return;
         tri_hit[t] = 1;
         if (!last_tri) return;
-        const Unit w = decode_unit(r, t, rel);
+        const Unit w = decode_unit(r, t, rel, ext ? ext[t] : 0u);
         const uint64_t row = (uint64_t)g.dim[0] * ((uint64_t)w.y + (uint64_t)g.dim[1] * w.z);
         while (mask) {
             const uint32_t b = __ffs(mask) - 1;
@@ -1132,10 +1142,10 @@ __global__ __launch_bounds__(256) void k_mat_ids_calls(const TriRec* __restrict_
 }
 
 void launch_mat_last(const TriRec* recs, const uint32_t* unit_base, const uint32_t* block_tri, uint32_t ntri, const GridParams& g, const uint32_t* unit_mask,
-                     const uint32_t* words, const uint32_t* word_prefix, uint32_t* last_tri, uint8_t* tri_hit, hipStream_t s)
+                     const uint32_t* words, const uint32_t* word_prefix, uint32_t* last_tri, uint8_t* tri_hit, hipStream_t s, const uint32_t* ext)
 {
     if (!ntri) return;
-    VX_KL(k_mat_last, dim3(kMaxBlocks), dim3(256), 0, s, recs, unit_base, block_tri, ntri, g, unit_mask, words, word_prefix, last_tri, tri_hit);
+    VX_KL(k_mat_last, dim3(kMaxBlocks), dim3(256), 0, s, recs, unit_base, block_tri, ntri, g, unit_mask, words, word_prefix, last_tri, tri_hit, ext);
 }
 void launch_mat_ids(const uint32_t* last_tri, uint64_t n, const int32_t* tri_value, const int16_t* value_index, int16_t* out, hipStream_t s)
 {

@@ -93,60 +93,85 @@ __global__ __launch_bounds__(256) void k_oct_depths(const uint64_t* __restrict__
             if (i0 + e < (int64_t)n) ncount[i0 + e] = (uint8_t)(packed >> (8u * e));
 }
 
+// Only one item position in five or six starts a node, and what such a position costs is a chain of dependent loads (the galloping
+// searches): a wave first gathers the positions of its stretch that do start nodes -- ballot + prefix count into its own piece of
+// LDS -- and then works through that list with all lanes busy (3.0 -> 1 ms on the 75M-item list of BASELINE configs[4]).
+constexpr uint32_t kNodeStretch = 512;  // item positions per wave
+
 __global__ __launch_bounds__(256) void k_oct_nodes(const uint64_t* __restrict__ items, uint32_t n, int bits, const uint32_t* __restrict__ base,
                                                    vx_octree_node* __restrict__ nodes)
 {
-    const uint64_t gi = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (gi >= n) return;
-    const uint32_t i = (uint32_t)gi;
+    __shared__ uint32_t live[4][kNodeStretch];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint64_t p0 = ((uint64_t)blockIdx.x * 4u + wv) * kNodeStretch;
+    if (p0 >= n) return;
+    uint32_t nlive = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kNodeStretch / 64u; ++k) {
+        const uint64_t p = p0 + k * 64u + lane;
+        const bool act = p < n && base[p + 1u] != base[p];
+        const unsigned long long m = __ballot(act);
+        if (act) live[wv][nlive + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)p;
+        nlive += (uint32_t)__popcll(m);
+    }
+    // (a wave's LDS writes are visible to its own later reads: no barrier)
+  for (uint32_t e = lane; e < nlive; e += 64u) {
+    const uint32_t i = live[wv][e];
     const uint32_t b0 = base[i], nn = base[i + 1u] - b0;
-    if (!nn) return;
     const uint64_t code = items[i];
     const int d0 = i == 0u ? 0 : lcp_digits(items[i - 1u], code, bits) + 1;
-    uint32_t end_prev = n;
+    int64_t end_prev = (int64_t)n;
     for (uint32_t q = 0; q < nn; ++q) {
         const int d = d0 + (int)q;
-        const int shift = 3 * (bits - d);
-        const uint64_t pref = shift < 64 ? code >> shift : 0ull;
-        // end of the depth-d run that starts at i: inside the end of the shallower run
-        uint32_t lo = i, hi = end_prev;  // item[lo] is in the run; the first item outside lies in (lo, hi]
-        for (uint64_t step = 1;; step <<= 1) {
-            const uint64_t p = (uint64_t)i + step;
-            if (p >= hi) break;
-            if ((shift < 64 ? items[p] >> shift : 0ull) == pref) lo = (uint32_t)p; else { hi = (uint32_t)p; break; }
+        const int shift = 3 * (bits - d);  // 0 .. 63 (bits <= 21)
+        const uint64_t pref = code >> shift;
+        // end of the depth-d run that starts at i = the first position behind i whose prefix is LARGER (the items are sorted); it lies
+        // inside the end of the shallower run.  Galloping search from i: runs are short as a rule.
+        int64_t lo = (int64_t)i;   // prefix(item[lo]) == pref
+        int64_t hi = end_prev;     // prefix(item[hi]) > pref, or hi == the shallower run's end
+#pragma nounroll
+        for (int64_t step = 1; (int64_t)i + step < hi; step <<= 1) {
+            const int64_t p = (int64_t)i + step;
+            if ((items[p] >> shift) > pref) { hi = p; break; }
+            lo = p;
         }
-        while (hi - lo > 1u) {
-            const uint32_t mid = lo + ((hi - lo) >> 1);
-            if ((shift < 64 ? items[mid] >> shift : 0ull) == pref) lo = mid; else hi = mid;
+#pragma nounroll
+        while (hi - lo > 1) {
+            const int64_t mid = lo + ((hi - lo) >> 1);
+            if ((items[mid] >> shift) > pref) hi = mid; else lo = mid;
         }
         const uint32_t id = b0 + q;
         nodes[id].start = i;          // octTree.hpp:325-327
-        nodes[id].count = hi - i;
+        nodes[id].count = (uint32_t)(hi - (int64_t)i);
         end_prev = hi;
         if (d > 0) {
             uint32_t parent;
             if (q > 0u) parent = id - 1u;
             else {
-                // the node of depth d - 1 around i: its run starts at the smallest p whose first d - 1 digits equal i's
-                const int sp = 3 * (bits - (d - 1));
-                const uint64_t pp = sp < 64 ? code >> sp : 0ull;
-                uint32_t in = i;        // known inside
-                int64_t out = -1;       // known outside (or -1)
-                for (uint64_t step = 1;; step <<= 1) {
-                    if (step > i) break;  // (i - step < 0)
-                    const uint32_t p = i - (uint32_t)step;
-                    if ((sp < 64 ? items[p] >> sp : 0ull) == pp) in = p; else { out = (int64_t)p; break; }
+                // the node of depth d - 1 around i: its run starts at the smallest position whose first d - 1 digits are not SMALLER
+                // than i's (galloping backwards from i)
+                const int sp = shift + 3;
+                const uint64_t pp = code >> sp;
+                int64_t in = (int64_t)i;  // prefix(item[in]) == pp
+                int64_t out = -1;         // prefix(item[out]) < pp, or -1
+#pragma nounroll
+                for (int64_t step = 1; step <= (int64_t)i; step <<= 1) {
+                    const int64_t p = (int64_t)i - step;
+                    if ((items[p] >> sp) < pp) { out = p; break; }
+                    in = p;
                 }
-                while ((int64_t)in - out > 1) {
-                    const uint32_t mid = (uint32_t)(out + (((int64_t)in - out) >> 1));
-                    if ((sp < 64 ? items[mid] >> sp : 0ull) == pp) in = mid; else out = (int64_t)mid;
+#pragma nounroll
+                while (in - out > 1) {
+                    const int64_t mid = out + ((in - out) >> 1);
+                    if ((items[mid] >> sp) < pp) out = mid; else in = mid;
                 }
-                const int d0p = in == 0u ? 0 : lcp_digits(items[in - 1u], items[in], bits) + 1;
+                const int d0p = in == 0 ? 0 : lcp_digits(items[in - 1], items[in], bits) + 1;
                 parent = base[in] + (uint32_t)((d - 1) - d0p);
             }
             nodes[parent].children[(uint32_t)(code >> shift) & 7u] = id;  // octTree.hpp:343,351
         }
     }
+  }
 }
 
 // first position in [lo, hi) whose octant at `shift` is >= c
@@ -278,7 +303,7 @@ void launch_oct_depths(const uint64_t* items, uint32_t nitems, uint32_t bits, ui
 void launch_oct_nodes(const uint64_t* items, uint32_t nitems, uint32_t bits, const uint32_t* base, vx_octree_node* nodes, hipStream_t s)
 {
     if (!nitems) return;
-    VX_KL(k_oct_nodes, dim3((nitems + 255) / 256), dim3(256), 0, s, items, nitems, (int)bits, base, nodes);
+    VX_KL(k_oct_nodes, dim3((nitems + 4u * kNodeStretch - 1u) / (4u * kNodeStretch)), dim3(256), 0, s, items, nitems, (int)bits, base, nodes);
 }
 
 // Builds the node array on the device.  items: sorted Morton codes (device).  On success *nodes_out is a hipMalloc'ed array

@@ -145,8 +145,9 @@ __global__ __launch_bounds__(1024) void k_rank(const float* __restrict__ t, cons
             if (normal_out) {
                 const uint64_t XY = (uint64_t)g.dim[0] * g.dim[1];
                 const uint32_t z = (uint32_t)(i / XY);
-                const uint32_t rem = (uint32_t)(i - (uint64_t)z * XY);
-                const uint32_t y = rem / g.dim[0], x = rem - y * g.dim[0];
+                const uint64_t rem = i - (uint64_t)z * XY;  // (X * Y may exceed 32 bits on a long thin grid)
+                const uint32_t y = (rem >> 32) ? (uint32_t)(rem / g.dim[0]) : (uint32_t)rem / g.dim[0];
+                const uint32_t x = (uint32_t)(rem - (uint64_t)y * g.dim[0]);
                 float bb[6], ox, oy, oz, dx, dy, dz;
                 cell_aabb(g, x, y, z, bb);
                 load_ray(rays == nullptr, r, rays, cam, ox, oy, oz, dx, dy, dz);

@@ -100,6 +100,85 @@ def test_octree(gpu, name, vs, max_items):
     assert np.array_equal(mn, r["root_min"]) and np.array_equal(mx, r["root_max"])
 
 
+@pytest.mark.parametrize("ntri,grid,max_items", [(20000, 256, 16), (200000, 512, 16), (200000, 512, 3), (60000, 256, 64), (60000, 256, 65),
+                                                 (60000, 256, 1000)])
+def test_octree_node_array_large(gpu, ntri, grid, max_items):
+    """Octree node arrays of 10^5 .. 10^6 items (the direct node build's galloping searches cross many workgroups; max_items <= 64
+    takes the direct form, larger values the level-by-level form): items and all 40-byte nodes against Octree::buildNodeRecursive
+    restated (run on the sorted items)."""
+    v, t = vx_scenes.soup(ntri, seed=4, edge=1.5 / grid)
+    vs = np.float32(1.0 / grid)
+    o = gpu.Octree(gpu.Mesh.from_arrays(v, t), vs, max_items)
+    h = oracle.hits(v, t, vs, threads=4, sat=0)
+    oitems = np.sort(oracle.morton3d_np(h[:, 0], h[:, 1], h[:, 2]))
+    assert np.array_equal(o.items(), oitems)
+    gi = oracle.grid_info(v, vs)
+    ref = oracle.octree_nodes_from_sorted_items(oitems, int(np.ceil(np.log2(max(gi["dim"])))), max_items)
+    nodes = o.nodes()
+    assert len(nodes) == len(ref) and nodes.tobytes() == ref.tobytes()
+    assert o.memory_bytes() == 8 * len(oitems) + 40 * len(ref)
+
+
+def long_thin_mesh(ncells=100_000, ntri=4000, seed=9):
+    """A mesh 100 000 x 8 x 8 voxels long (voxel size 1): small triangles all along x, a few long ones spanning > 65535 cells."""
+    rng = np.random.default_rng(seed)
+    c = np.stack([rng.uniform(0.0, ncells, ntri), rng.uniform(0.5, 7.5, ntri), rng.uniform(0.5, 7.5, ntri)], 1)
+    tri = (c[:, None, :] + rng.uniform(-1.7, 1.7, (ntri, 3, 3))).astype(np.float32)
+    long_ = np.array([[[10.3, 1.2, 1.1], [99000.7, 6.5, 2.2], [70000.1, 2.0, 6.9]],
+                      [[65530.2, 0.7, 7.2], [65541.9, 7.1, 0.4], [65536.0, 4.0, 4.0]],
+                      [[200.5, 7.7, 0.3], [80123.4, 0.2, 7.6], [80124.4, 0.9, 7.1]]], np.float32)
+    tri = np.concatenate([tri, long_])
+    tri[:, :, 0] = np.clip(tri[:, :, 0], 0.0, float(ncells))
+    tri[:, :, 1:] = np.clip(tri[:, :, 1:], 0.0, 8.0)
+    tri[0, 0] = (0.0, 0.0, 0.0)                      # pin the bounding box: exactly ncells x 8 x 8 cells of size 1
+    tri[1, 0] = (float(ncells), 8.0, 8.0)
+    v = np.ascontiguousarray(tri.reshape(-1, 3))
+    t = np.arange(len(v), dtype=np.int32).reshape(-1, 3)
+    return v, t
+
+
+def test_axis_above_65535_cells(gpu):
+    """A 100 000 x 8 x 8-cell grid (the reference's dims are size_t, VoxelBuilder.hpp:347-349; its Octree takes up to 2^21 cells
+    per axis, octTree.hpp:577-588): Bool, AABBstruct-sized, Vec and Octree bit-equal to the oracle, incl. the Morton low-16-bit
+    quirk (octTree.hpp:211-218) for x >= 65536; beyond 2^21 cells the Octree reports the reference's Morton-bits error."""
+    v, t = long_thin_mesh()
+    vs = np.float32(1.0)
+    mesh = gpu.Mesh.from_arrays(v, t)
+    for sat in (0, 1):
+        g = gpu.Grid.voxelize(mesh, vs, gpu.GRID_BOOL, sat_variant=sat)
+        ow, calls, gi = oracle.build_bool(v, t, vs, threads=0 if sat == 0 else 2)
+        assert gi["dim"] == (100_000, 8, 8) and g.describe()["dim"] == gi["dim"]
+        assert np.array_equal(g.bitmask(), ow) and g.describe()["set_calls"] == calls
+        assert g.aabbs().tobytes() == oracle.bool_aabbs(ow, gi, vs).tobytes()
+    gv = gpu.Grid.voxelize(mesh, vs, gpu.GRID_VEC)
+    ov = oracle.build_vec(v, t, vs)
+    assert gv.aabbs().tobytes() == ov.tobytes() and (ov["mn"][:, 0] > 65536).any()
+    o = gpu.Octree(mesh, vs)
+    r = oracle.octree(v, t, vs, threads=2)
+    assert np.array_equal(o.items(), r["items"]) and o.nodes().tobytes() == r["nodes"].tobytes()
+    assert o.aabbs().tobytes() == r["aabbs"].tobytes() and o.memory_bytes() == r["bytes"]
+    # per-voxel material ids on the wide grid (the unit kernels of that pass decode the same ranges)
+    recs = np.zeros(5, dtype=gpu.MATERIAL)
+    recs["diffuse"][:, 0] = np.arange(5) / 8.0
+    ids = (np.arange(len(t)) % 5).astype(np.int32)
+    mesh.set_materials(recs, ids)
+    tv, nvalues, _ = _value_ids(recs, ids)
+    gm = gpu.Grid.voxelize(mesh, vs, gpu.GRID_BOOL, materials=True)
+    oids, order = oracle.material_ids(v, t, vs, tv, nvalues)
+    assert np.array_equal(gm.bitmask(), ow) and np.array_equal(gm.materials()[1], oids)
+    # rays on such a grid are refused, not wrong
+    with pytest.raises(gpu.VxError) as ei:
+        gm.trace(vx_scenes.random_rays(16, gi["bmin"], gi["bmax"], seed=1))
+    assert ei.value.status == 9   # VX_ERR_UNSUPPORTED
+    # the reference's own limit: more than 2^21 cells on an axis
+    with pytest.raises(gpu.VxError) as ei:
+        gpu.Octree(mesh, np.float32(100_000 / (2 ** 21 + 5000.0)))
+    assert ei.value.status == 5   # VX_ERR_MORTON_BITS
+    with pytest.raises(gpu.VxError) as ei:
+        gpu.Grid.voxelize(mesh, np.float32(100_000 / (2 ** 21 + 5000.0)))
+    assert ei.value.status == 8   # VX_ERR_CAPACITY
+
+
 def test_empty_inputs(gpu):
     flat_v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
     tri = np.array([[0, 1, 2]], np.int32)

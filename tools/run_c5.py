@@ -24,7 +24,18 @@ log("VoxelGridBool build %.3f s: dim %s occupied %d set_calls %d  -> %.0f Mvoxel
 t0 = time.time(); g.revoxelize(mesh, vs); d = g.describe(); t1 = time.time()
 log("  (steady state, buffers reused) %.3f s -> %.0f Mvoxels/s" % (t1 - t0, np.prod(d["dim"]) / (t1 - t0) / 1e6))
 t0 = time.time(); o = voxhip.Octree(mesh, vs); t1 = time.time()
-log("Octree build %.3f s: items %d nodes %d bytes %d" % (t1 - t0, o.num_items, o.num_nodes, o.memory_bytes()))
+log("Octree build %.4f s (first build: cold memory pool): items %d nodes %d bytes %d" % (t1 - t0, o.num_items, o.num_nodes, o.memory_bytes()))
+del o
+tb = []
+for _ in range(3):
+    t0 = time.time(); o = voxhip.Octree(mesh, vs); tb.append(time.time() - t0)
+    if _ < 2: del o
+log("Octree build, warm pool (3 runs): %s ms" % ", ".join("%.2f" % (1e3 * x) for x in tb))
+if os.environ.get("C5_KERNELS"):
+    voxhip.profile_reset(); voxhip.profile_enable(True)
+    o2 = voxhip.Octree(mesh, vs); torch.cuda.synchronize(); voxhip.profile_enable(False)
+    log("octree kernels (ms): " + " ".join("%s %.3f" % (nm, ms) for nm, (ms, c) in sorted(voxhip.profile_read().items())))
+    del o2
 assert o.num_items == d["set_calls"], "octree items must equal the number of setVoxel calls (duplicates kept)"
 items = o.items()
 assert np.all(items[:-1] <= items[1:]), "items not sorted"
