@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--cpu-runs", type=int, default=5, help="repetitions of the CPU voxelizer timings (mean and min are reported)")
     ap.add_argument("--verify-rays", type=int, default=1000)
     ap.add_argument("--big-rays", type=int, default=8_000_000, help="extra untimed-for-`value` measurement: trace throughput on a large batch (0 = skip)")
+    ap.add_argument("--no-context", action="store_true",
+                    help="skip the untimed-for-`value` context block (interior camera on this scene, BASELINE configs[1] and configs[4] trace rates)")
     ap.add_argument("--c4-grid", type=int, default=1024, help="N>1: also measure the sharded build + exchange at this resolution (0 = skip)")
     ap.add_argument("--flavour", default="vec", choices=["vec", "bool"],
                     help="vec: VoxelGridVec build (BASELINE configs[2]); bool: VoxelGridBool build + K4 getAabbs (the app's default path)")
@@ -132,6 +134,114 @@ def load_profile_json(suffix):
         except (OSError, ValueError):
             continue
     return None, None
+
+
+def trace_context(voxhip, vx_scenes, grid, verts, vs, dev, use_oracle, c5=True):
+    """What the headline ray batch does not show (it starts outside a scene closed on five sides: every ray hits the hull).  Untimed
+    for `value`, rank 0 at N = 1 only:
+      trace_interior  the reference's own use (raytrace.rgen:41-51, main.cpp:92): a camera INSIDE the hall, 1280 x 720, two frames,
+                      primary rays generated in the kernel
+      trace_c2        BASELINE configs[1]: blob70k at 256^3, 1M random rays
+      trace_c5        BASELINE configs[4]: 10M-triangle soup at 2048^3, octree build, 100M coherent primary rays
+    each with its hit rate and -- from the oracle's grid walk (the scalar statement of k_walk's traversal) on a sample of the same
+    rays -- the mean slab steps per ray."""
+    out = {}
+    oracle = None
+    if use_oracle:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle
+
+    def timed_ms(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    def walk_stats(words, gi, vsz, sample):
+        if oracle is None or not len(sample):
+            return None
+        t, p, st = oracle.trace_walk(words, gi, vsz, sample, want_stats=True)
+        n = float(len(sample))
+        return {"rays_sampled": len(sample), "block_slabs": round(st["block_slabs"] / n, 2), "brick_slabs": round(st["brick_slabs"] / n, 2),
+                "cell_slabs": round(st["cell_slabs"] / n, 2), "exact_tests": round(st["exact_tests"] / n, 2),
+                "slab_steps": round((st["block_slabs"] + st["brick_slabs"] + st["cell_slabs"]) / n, 2), "hit_rate": round(float((t > 0).mean()), 4)}
+
+    # ---- interior camera on the bench scene
+    W, H = 1280, 720
+    cams = [vx_scenes.camera_matrices(**c) for c in vx_scenes.INTERIOR_CAMERAS]
+    d_t = torch.empty(W * H, dtype=torch.float32, device=dev)
+    d_p = torch.empty(W * H, dtype=torch.int32, device=dev)
+    ms, hits = 0.0, 0
+    for vi, pi in cams:
+        ms += timed_ms(lambda: grid.trace_primary_device(vi, pi, W, H, d_t.data_ptr(), d_p.data_ptr()), 5)
+        hits += int((d_t > 0).sum().item())
+    n = len(cams) * W * H
+    st = None
+    if oracle is not None:
+        gi = oracle.grid_info(verts, vs)
+        pix = np.random.default_rng(5).choice(W * H, 20000, replace=False).astype(np.uint64)
+        st = walk_stats(grid.bitmask(), gi, vs, np.concatenate([oracle.primary_rays_pixels(vi, pi, W, H, pix) for vi, pi in cams]))
+    out["trace_interior"] = {"workload": "camera inside the hall (raytrace.rgen camera model), %d frames of %dx%d primary rays generated in the kernel" % (len(cams), W, H),
+                             "rays": n, "ms": round(ms, 4), "mrays_per_s": round(n / (ms * 1e-3) / 1e6, 1), "hit_rate": round(hits / n, 4), "walk": st}
+    del d_t, d_p
+    # ---- BASELINE configs[1]
+    v2, t2 = vx_scenes.scene("blob70k")
+    vs2 = np.float32(2.0 / 256)
+    g2 = voxhip.Grid.voxelize(voxhip.Mesh.from_arrays(v2, t2), vs2)
+    r2 = vx_scenes.random_rays(1_000_000, v2.min(0), v2.max(0), seed=2)
+    d_r2 = torch.from_numpy(r2).to(dev)
+    d_t2 = torch.empty(len(r2), dtype=torch.float32, device=dev)
+    d_p2 = torch.empty(len(r2), dtype=torch.int32, device=dev)
+    ms2 = timed_ms(lambda: g2.trace_device(d_r2.data_ptr(), len(r2), d_t2.data_ptr(), d_p2.data_ptr()), 5)
+    st2 = walk_stats(g2.bitmask(), oracle.grid_info(v2, vs2), vs2, r2[:20000]) if oracle is not None else None
+    out["trace_c2"] = {"workload": "BASELINE configs[1]: blob70k (%d tris) @ 256^3, 1M random rays" % len(t2), "grid_dim": list(g2.describe()["dim"]), "rays": len(r2),
+                       "ms": round(ms2, 4), "mrays_per_s": round(len(r2) / (ms2 * 1e-3) / 1e6, 1), "hit_rate": round(float((d_t2 > 0).float().mean().item()), 4), "walk": st2}
+    del g2, d_r2, d_t2, d_p2
+    # ---- BASELINE configs[4]
+    if c5:
+        NT, G = 10_000_000, 2048
+        v5, t5 = vx_scenes.soup(NT, seed=4, edge=1.5 / G)
+        vs5 = np.float32(1.0 / G)
+        dv, dt_ = torch.from_numpy(v5).to(dev), torch.from_numpy(t5).to(dev)
+        m5 = voxhip.Mesh.from_device(dv.data_ptr(), len(v5), dt_.data_ptr(), len(t5), keep=(dv, dt_))
+        torch.cuda.synchronize()
+        g5 = voxhip.Grid.voxelize(m5, vs5, voxhip.GRID_BOOL)
+        t0 = time.perf_counter()
+        g5.revoxelize(m5, vs5)
+        d5 = g5.describe()
+        build_ms = (time.perf_counter() - t0) * 1e3
+        o = voxhip.Octree(m5, vs5)
+        del o
+        tb = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            o = voxhip.Octree(m5, vs5)
+            tb.append((time.perf_counter() - t0) * 1e3)
+            ni, nn = o.num_items, o.num_nodes
+            del o
+        vi, pi = vx_scenes.camera_matrices(eye=(1.55, 1.25, -0.85), ctr=(0.5, 0.5, 0.5), fov_deg=38.0, aspect=1.0)  # (tests/test_gpu_configs.py: C5)
+        W5, H5, tiles = 10000, 10000, 1
+        d_t5 = torch.empty(W5 * H5, dtype=torch.float32, device=dev)
+        d_p5 = torch.empty(W5 * H5, dtype=torch.int32, device=dev)
+        ms5 = timed_ms(lambda: g5.trace_primary_device(vi, pi, W5, H5, d_t5.data_ptr(), d_p5.data_ptr()), 2)
+        hr5 = float((d_t5 > 0).float().mean().item())
+        st5 = None
+        if oracle is not None:
+            pix = np.random.default_rng(6).choice(W5 * H5, 20000, replace=False).astype(np.uint64)
+            st5 = walk_stats(g5.bitmask(), oracle.grid_info(v5, vs5), vs5, oracle.primary_rays_pixels(vi, pi, W5, H5, pix))
+        nv = float(np.prod(d5["dim"]))
+        out["trace_c5"] = {"workload": "BASELINE configs[4]: 10M-triangle soup @ 2048^3, octree (sparse) path, %d launch of %dx%d coherent primary rays" % (tiles, W5, H5),
+                           "grid_dim": list(d5["dim"]), "occupied_voxels": d5["occupied"], "voxelize_bool_ms_host_clock": round(build_ms, 3),
+                           "mvoxels_per_s": round(nv / (build_ms * 1e-3) / 1e6, 1), "octree_build_ms_host_clock": [round(x, 3) for x in tb], "octree_items": ni,
+                           "octree_nodes": nn, "rays": tiles * W5 * H5, "ms": round(ms5, 3), "mrays_per_s": round(tiles * W5 * H5 / (ms5 * 1e-3) / 1e6, 1),
+                           "hit_rate": round(hr5, 4), "walk": st5}
+        del g5, m5, dv, dt_, d_t5, d_p5
+    return out
 
 
 def main():
@@ -331,6 +441,9 @@ def main():
         torch.cuda.synchronize()
         big = {"rays": a.big_rays, "ms": round(e0.elapsed_time(e1) / 3, 4), "mrays_per_s": round(a.big_rays * 3 / (e0.elapsed_time(e1) * 1e-3) / 1e6, 1)}
         del d_rb, d_tb, d_pb
+    context = None
+    if rank == 0 and world == 1 and not sharded and not a.no_context and a.scene == "atrium262k":
+        context = trace_context(voxhip, vx_scenes, grid, verts, vs, dev, use_oracle=not a.no_cpu_baseline)
     if rank != 0:
         if dist is not None:
             dist.barrier()
@@ -410,7 +523,7 @@ def main():
         "stages_ms": {"voxelize": round(float(stage_ms[0]), 4), "exchange": round(float(stage_ms[1]), 4),
                       "get_aabbs": round(float(stage_ms[2]), 4), "trace": round(float(stage_ms[3]), 4)},
         "occupied_voxels": gd["occupied"], "aabbs_returned": int(nocc), "set_calls": gd["set_calls"], "ray_hits_rank0": hits,
-        "trace_large_batch": big,
+        "trace_large_batch": big, "trace_context": context,
         "kernel_rooflines": {k: {"achieved_GBps": round(alg_bytes[k] / (kern_all[k][0] / max(kern_all[k][1], 1) * 1e-3) / 1e9, 1),
                                  "frac_of_8TBps": round(alg_bytes[k] / (kern_all[k][0] / max(kern_all[k][1], 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
                              for k in alg_bytes if k in kern_all},

@@ -239,6 +239,11 @@ def camera_matrices(eye=(6.16636, 2.42256, -3.15471), ctr=(0.0, 1.0, 0.0), up=(0
     return vi, pi
 
 
+# Cameras INSIDE the atrium hall (bbox [-16,16] x [0,32] x [-16,16], open towards +z): what the reference renders -- its camera stands in
+# the scene (main.cpp:92) -- as opposed to bench.py's headline batch, whose rays start outside a scene closed on five sides.
+INTERIOR_CAMERAS = (dict(eye=(0.0, 6.0, 14.0), ctr=(-2.0, 10.0, -16.0)), dict(eye=(-10.0, 12.0, 10.0), ctr=(8.0, 8.0, -12.0)))
+
+
 def write_obj(path, verts, tris, header="synthetic scene"):
     v = np.asarray(verts, dtype=np.float32)
     t = np.asarray(tris, dtype=np.int64) + 1

@@ -246,6 +246,37 @@ def test_c3_bench_workload_ray_parity(gpu):
     assert 0.2 < (oti > 0).mean()
 
 
+def test_interior_camera_batch(gpu):
+    """bench.py's `trace_interior` workload: the reference's camera model (raytrace.rgen:41-51) standing INSIDE the hall, 1280 x 720.
+    Every pixel's ray, given explicitly, must trace bit-equal to the oracle's grid walk (and a sample to the brute force); the
+    in-kernel generated rays must agree on hit / miss and on t within the north-star tolerance (1e-5)."""
+    import torch
+    v, t = vx_scenes.scene("atrium262k")
+    vs = np.float32(32.0 / 512)
+    g = gpu.Grid.voxelize(gpu.Mesh.from_arrays(v, t), vs)
+    ow, _, gi = oracle.build_bool(v, t, vs, threads=min(NCORES, 32))
+    assert np.array_equal(g.bitmask(), ow)
+    oa = oracle.bool_aabbs(ow, gi, vs)
+    W, H = 1280, 720
+    dev = torch.device("cuda", 0)
+    for cam in vx_scenes.INTERIOR_CAMERAS:
+        vi, pi = vx_scenes.camera_matrices(**cam)
+        rays = oracle.primary_rays(vi, pi, W, H)
+        te, pe, _ = g.trace(rays)
+        wt, wp = oracle.trace_walk(ow, gi, vs, rays, threads=NCORES)
+        assert np.array_equal(te, wt) and np.array_equal(pe, wp)
+        sel = np.random.default_rng(91).choice(W * H, 1500, replace=False)
+        bt, bp = oracle.trace_brute(oa, rays[sel], threads=NCORES)
+        assert np.array_equal(te[sel], bt) and np.array_equal(pe[sel], bp)
+        d_t = torch.empty(W * H, dtype=torch.float32, device=dev)
+        d_p = torch.empty(W * H, dtype=torch.int32, device=dev)
+        g.trace_primary_device(vi, pi, W, H, d_t.data_ptr(), d_p.data_ptr())
+        torch.cuda.synchronize()
+        tk = d_t.cpu().numpy()
+        assert np.array_equal(tk > 0, te > 0) and np.allclose(tk, te, rtol=0, atol=1e-5)
+        assert (te > 0).mean() > 0.8            # the camera looks at the back of the hall: nearly every pixel sees a voxel
+
+
 # ---------------------------------------------------------------------------------------------- BASELINE configs[3]: 1024^3
 def test_c4_atrium_1024_rays(gpu):
     """atrium262k at exactly 1024^3 traces through k_trace<false>; sampled random / inside / corner rays against the brute
