@@ -88,12 +88,18 @@ typedef struct vx_voxelize_opts {
     uint64_t tri_begin;   /* only triangles [tri_begin, tri_end) are voxelized (both 0 = all).                 */
     uint64_t tri_end;
     void* stream;         /* hipStream_t the grid's kernels run on */
+    int32_t shard_rank;   /* word shard BY RANK: with shard_world > 1 (and word_begin == word_end == 0) the build derives            */
+    int32_t shard_world;  /* [word_begin, word_end) = vx_shard_words(num_words, shard_rank, shard_world) from its own bounding-box   */
+                          /* pass -- the caller need not know the grid's word count beforehand (0 or 1: whole grid)                 */
 } vx_voxelize_opts;
 
 /* vx_voxelize_opts.flags */
 #define VX_VOXELIZE_MATERIALS 1 /* also fill the per-voxel material ids: setVoxel -> addMatrialIfNeeded, the plumbing the reference keeps
                                    commented out (VoxelBuilder.hpp:375-395, voxelgridBool.cpp:64, voxelgridAABBstruct.cpp:31,
-                                   voxelgridVecEncoding.cpp:27).  Not available for word / triangle shards. */
+                                   voxelgridVecEncoding.cpp:27).  A word / triangle shard leaves the ids PENDING: the index a material
+                                   gets is the order of its first use over the WHOLE build, so the shards' first uses are combined
+                                   first (vx_grid_material_first_use -> element-wise minimum over the shards ->
+                                   vx_grid_finish_materials); an unsharded build finishes by itself. */
 
 /* ---- library ------------------------------------------------------------------------------------------- */
 const char* vx_last_error(void);
@@ -144,6 +150,30 @@ vx_status vx_voxelize_into(const vx_mesh* mesh, float voxel_size, const vx_voxel
  * VX_GRID_AABBSTRUCT only: VX_GRID_VEC's list order needs triangle shards (vx_voxelize_opts.tri_begin/tri_end). */
 vx_status vx_voxelize_multi(const vx_mesh* mesh, float voxel_size, vx_grid_kind kind, int sat_variant, const int* devices, int num_devices, int all_gather,
                             vx_grid** out_grids);
+/* The same as a STEADY-STATE entry: vx_multi_create uploads the mesh to every listed device once and starts one worker thread and
+ * one grid handle per rank; every vx_multi_voxelize then rebuilds the grid (any voxel size) with no upload, no thread start and --
+ * when sizes repeat -- no allocation: each rank derives its word shard from its own bounding-box pass (vx_voxelize_opts.shard_rank /
+ * shard_world), the shards are exchanged as peer copies, the destination grids (rank 0, or every rank with all_gather) refresh word
+ * prefix and traversal structure.  opts: sat_variant, flags (VX_VOXELIZE_MATERIALS: the shards' first uses are combined and the ids
+ * gathered in shard order, see vx_grid_finish_materials) and stream are honoured; the shard fields must be 0.
+ * vx_multi_grid: the context's grid of rank k (owned by the context, valid until the next vx_multi_voxelize / vx_multi_free);
+ * vx_multi_release_grid hands it to the caller (vx_grid_free), the context then no longer rebuilds that rank. */
+typedef struct vx_multi vx_multi;
+vx_status vx_multi_create(const vx_mesh* mesh, const int* devices, int num_devices, vx_grid_kind kind, vx_multi** out);
+vx_status vx_multi_voxelize(vx_multi* m, float voxel_size, const vx_voxelize_opts* opts /*NULL ok*/, int all_gather);
+vx_grid* vx_multi_grid(vx_multi* m, int rank);
+vx_grid* vx_multi_release_grid(vx_multi* m, int rank);
+void vx_multi_free(vx_multi* m);
+
+/* Materials of a SHARDED build (VX_VOXELIZE_MATERIALS with a word or triangle shard).  addMatrialIfNeeded (voxelgrid.hpp:102-114)
+ * numbers materials in the order of their first setVoxel call over the whole build; a shard only sees its own calls.
+ * vx_grid_material_first_use: per material VALUE of the mesh (value 0 = MaterialObj{}, then the mesh's records de-duplicated by
+ * operator==, in record order) the index of the first triangle that carries it into a setVoxel call of this shard, -1 = none.
+ * vx_grid_finish_materials: given the element-wise minimum of those arrays over all shards (-1 = unused everywhere) the grid fills
+ * getMatrials() and the ids of ITS voxels / calls (ascending voxel order resp. call order: the shards' id arrays concatenated in
+ * shard order are the unsharded build's).  Also callable on an unsharded build (a no-op: it has finished by itself). */
+vx_status vx_grid_material_first_use(const vx_grid* g, int64_t* out, uint64_t capacity, uint64_t* count);
+vx_status vx_grid_finish_materials(vx_grid* g, const int64_t* first_use_min, uint64_t count);
 
 /* ---- grid: replaces VoxelGrid<T> and its three subclasses ------------------------------------------------ */
 /* VoxelGrid ctor (voxelgrid.hpp:52-62): an empty grid of x*y*z voxels */

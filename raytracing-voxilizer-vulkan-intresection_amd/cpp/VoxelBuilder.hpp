@@ -98,8 +98,19 @@ public:
         opts.flags = m_materials ? VX_VOXELIZE_MATERIALS : 0;
         vx_grid* g = nullptr;
         if (m_devices.size() > 1) {
-            if (m_materials) throw std::invalid_argument("withMaterials() and withDevices() cannot be combined");
-            vxdetail::check(vx_voxelize_multi(m_mesh.get(), voxelSize, vxdetail::kind_of<T>(), opts.sat_variant, m_devices.data(), (int)m_devices.size(), 0, &g));
+            // word shards on the listed devices, peer copies to the first; with materials the shards' first uses are combined and
+            // the ids gathered in shard order (vx_multi_voxelize).  The grid handed back is the first device's.
+            vx_multi* mc = nullptr;
+            vxdetail::check(vx_multi_create(m_mesh.get(), m_devices.data(), (int)m_devices.size(), vxdetail::kind_of<T>(), &mc));
+            const vx_status st = vx_multi_voxelize(mc, voxelSize, &opts, 0);
+            if (st != VX_OK) {
+                const std::string err = vx_last_error();
+                vx_multi_free(mc);
+                if (st == VX_ERR_INVALID_ARG) throw std::invalid_argument(err);
+                throw std::runtime_error(err);
+            }
+            g = vx_multi_release_grid(mc, 0);
+            vx_multi_free(mc);
         } else
             vxdetail::check(vx_voxelize(m_mesh.get(), voxelSize, vxdetail::kind_of<T>(), &opts, &g));
         vxdetail::GridHandle h = vxdetail::adopt(g);

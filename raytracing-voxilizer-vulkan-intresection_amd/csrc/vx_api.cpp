@@ -3,7 +3,9 @@
 #include "vx_internal.h"
 
 #include <cmath>
+#include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -292,6 +294,16 @@ struct vx_grid {
     std::vector<vx_material> materials;  // m_materials: distinct values in first-use order (VX_VOXELIZE_MATERIALS builds only)
     uint64_t mat_count = 0;              // entries of matids
     bool has_materials = false;
+    // a VX_VOXELIZE_MATERIALS build in two halves: what the build itself knows (per value the first triangle of this shard that uses
+    // it; the last triangle per voxel resp. the unit masks stay in mattmp / umask / hbase) and the finish (finish_materials)
+    bool mat_pending = false;
+    std::vector<long long> mat_first_use;
+    std::vector<vx_material> mat_values;   // the mesh's material values at build time
+    const int32_t* mat_dtv = nullptr;      // per-triangle value ids of this build's triangle range (device, owned by the mesh)
+    uint32_t mat_ntri = 0;
+    uint64_t mat_nids = 0;
+    bool mat_gathered = false;             // multi-GPU build: the ids of ALL shards, gathered in shard order, live in mattmp
+    uint64_t mat_gather_count = 0;
     bool coarse_valid = false, prefix_valid = false /*word_prefix queued or done*/, occupied_known = false, counts_valid = true;
     uint64_t occupied = 0, set_calls = 0, host_set_calls = 0;
     uint64_t vec_count = 0;
@@ -453,7 +465,7 @@ constexpr uint64_t kMaxVoxels = 1ull << 37;  // 16 GiB of bitmask
 vx_status setup_launch(const vx_mesh* m, const vx::GridParams& g, int sat, uint64_t tb, uint32_t ntri, uint32_t zlo, uint32_t zhi, DevBuf& recs,
                        DevBuf& units, DevBuf& ubase, DevBuf& scantmp, Mail* mail, hipStream_t s, DevBuf& ext, const vx::DevGrid* dgrid = nullptr,
                        unsigned long long mail_tag = 0, bool* tagged = nullptr, void* clear = nullptr, uint64_t clear_bytes = 0,
-                       uint64_t shard_wb = 0, uint64_t shard_we = 0)
+                       uint64_t shard_wb = 0, uint64_t shard_we = 0, uint32_t shard_rank = 0, uint32_t shard_world = 0)
 {
     VX_HIP(recs.ensure((size_t)ntri * sizeof(vx::TriRec) + 64));
     VX_HIP(ext.ensure(((size_t)ntri + 1) * 4));  // high bits of the candidate ranges (read only when an axis has more than 65535 cells)
@@ -461,7 +473,7 @@ vx_status setup_launch(const vx_mesh* m, const vx::GridParams& g, int sat, uint6
     VX_HIP(ubase.ensure(((size_t)ntri + 2) * 4));
     VX_HIP(ensure_scan_tmp(scantmp, vx::scan_tmp_bytes(ntri), s));
     vx::launch_tri_setup(m->dv, m->di, tb, ntri, g, sat, zlo, zhi, recs.as<vx::TriRec>(), units.as<uint32_t>(), s, dgrid, clear, clear_bytes, shard_wb, shard_we,
-                         ext.as<uint32_t>());
+                         ext.as<uint32_t>(), shard_rank, shard_world);
     const bool tg = vx::launch_scan_u32(units.as<uint32_t>(), ubase.as<uint32_t>(), ntri, false, scantmp.p, &mail->units, s, true, mail_tag);
     if (tagged) *tagged = tg && mail_tag != 0;
     return VX_OK;
@@ -577,6 +589,47 @@ vx_status init_grid_storage(vx_grid* g, bool clear = true)
     g->coarse_valid = g->prefix_valid = g->occupied_known = false;
     g->counts_valid = true;
     g->occupied = g->set_calls = g->host_set_calls = g->vec_count = 0;
+    return VX_OK;
+}
+
+// Second half of a VX_VOXELIZE_MATERIALS build: addMatrialIfNeeded (voxelgrid.hpp:102-114) gives a material the next index when the
+// first setVoxel call carrying it arrives, i.e. values are numbered by the first triangle that uses them; then triangle -> value ->
+// index for every voxel (Bool / AABBstruct: the last triangle per voxel) or call (Vec).
+vx_status finish_materials(vx_grid* g, const long long* first_use, size_t nvalues)
+{
+    if (!g->mat_pending) return VX_OK;
+    if (nvalues != g->mat_values.size()) return fail(VX_ERR_INVALID_ARG, "first-use array does not match the mesh's material values");
+    DeviceGuard dg(g->device);
+    hipStream_t s = g->stream;
+    std::vector<size_t> used;
+    for (size_t v = 0; v < nvalues; ++v)
+        if (first_use[v] >= 0) used.push_back(v);
+    std::sort(used.begin(), used.end(), [&](size_t a, size_t b) { return first_use[a] < first_use[b]; });
+    std::vector<int16_t> vindex(nvalues, (int16_t)-1);
+    g->materials.clear();
+    for (size_t k = 0; k < used.size(); ++k) {
+        vindex[used[k]] = (int16_t)k;
+        g->materials.push_back(g->mat_values[used[k]]);
+    }
+    const uint32_t ntri = g->mat_ntri;
+    const bool vec = g->kind == VX_GRID_VEC;
+    uint8_t* base = g->mattmp.as<uint8_t>();
+    uint32_t* last_tri = vec ? nullptr : reinterpret_cast<uint32_t*>(base);
+    uint8_t* tri_hit = base + (vec ? 0 : (size_t)g->mat_nids * 4);
+    int16_t* value_index = reinterpret_cast<int16_t*>(tri_hit + (((size_t)ntri + 63) & ~(size_t)63));
+    VX_HIP(hipMemcpyAsync(value_index, vindex.data(), vindex.size() * 2, hipMemcpyHostToDevice, s));
+    VX_HIP(g->matids.ensure((size_t)g->mat_nids * 2 + 16));
+    if (g->mat_nids) {
+        if (vec)
+            vx::launch_mat_ids_calls(g->recs.as<vx::TriRec>(), g->ubase.as<uint32_t>(), g->btri.as<uint32_t>(), ntri, g->umask.as<uint32_t>(), g->hbase.as<uint32_t>(),
+                                     g->mat_dtv, value_index, g->matids.as<int16_t>(), s);
+        else
+            vx::launch_mat_ids(last_tri, g->mat_nids, g->mat_dtv, value_index, g->matids.as<int16_t>(), s);
+    }
+    VX_HIP(hipStreamSynchronize(s));  // vindex lives on this stack frame
+    g->mat_count = g->mat_nids;
+    g->has_materials = true;
+    g->mat_pending = false;
     return VX_OK;
 }
 
@@ -744,11 +797,14 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
     hipStream_t s = g->stream;
     if (o.sat_variant != 0 && o.sat_variant != 1) return fail(VX_ERR_INVALID_ARG, "sat_variant must be 0 or 1");
     const bool want_mat = (o.flags & VX_VOXELIZE_MATERIALS) != 0;
-    if (want_mat && (o.word_begin || o.word_end || o.tri_begin || o.tri_end)) return fail(VX_ERR_UNSUPPORTED, "VX_VOXELIZE_MATERIALS is not available for sharded builds");
     if (want_mat) VX_TRY(mesh_material_values(mesh));
     g->has_materials = false;
+    g->mat_pending = false;
+    g->mat_gathered = false;
     g->materials.clear();
     g->mat_count = 0;
+    if (o.shard_world < 0 || (o.shard_world > 0 && (o.shard_rank < 0 || o.shard_rank >= o.shard_world))) return fail(VX_ERR_INVALID_ARG, "shard_rank / shard_world out of range");
+    const bool by_rank = o.shard_world > 1 && !(o.word_begin || o.word_end);
 
     VX_HIP(ensure_small(g->small));
     if (!g->mail) VX_HIP(mail_alloc(&g->mail));
@@ -760,7 +816,7 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
         te = o.tri_end;
     }
     const uint32_t ntri = (uint32_t)(te - tb);
-    const bool sharded_words = o.word_begin || o.word_end;
+    const bool sharded_words = o.word_begin || o.word_end || by_rank;
 
     // Unsharded build: K1 leaves origin + dims in device memory, so the triangle records and the unit scan are queued right
     // behind it and the host waits ONCE for the bbox and the unit count (every host round trip costs ~20 us of idle GPU: the
@@ -786,7 +842,7 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
         const bool clear_in_setup = g->words.p && (g->words.cap % 16) == 0 && g->words.cap / 256 <= (size_t)ntri;
         VX_TRY(setup_launch(mesh, gp, o.sat_variant, tb, ntri, 0, 0, g->recs, g->units, g->ubase, g->scantmp, g->mail, s, g->ext, &ds->dgrid, mtag, &units_tagged,
                             clear_in_setup ? g->words.p : nullptr, clear_in_setup ? g->words.cap : 0, sharded_words ? o.word_begin : 0,
-                            sharded_words ? o.word_end : 0));
+                            sharded_words ? o.word_end : 0, by_rank ? (uint32_t)o.shard_rank : 0u, by_rank ? (uint32_t)o.shard_world : 0u));
         if (clear_in_setup) cleared = g->words.cap;
         // the block table of the units: queued now, for as many blocks as the handle's table from the previous build holds, so that
         // it runs while the host waits for the unit total (redone by setup_finish should the table turn out too small)
@@ -816,16 +872,28 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
     const bool mask_is_clear = cleared >= mask_bytes;
 
     uint64_t wb = 0, we = g->g.nwords;
-    if (sharded_words) {
+    if (by_rank) {
+        vx_shard_words(g->g.nwords, o.shard_rank, o.shard_world, &wb, &we, nullptr);
+    } else if (sharded_words) {
         if (o.word_begin > o.word_end || o.word_end > g->g.nwords) return fail(VX_ERR_INVALID_ARG, "word shard out of range");
         wb = o.word_begin;
         we = o.word_end;
     }
+    const bool whole_build = wb == 0 && we == g->g.nwords && tb == 0 && te == mesh->nt;
+    auto no_calls_materials = [&]() -> vx_status {  // a build without a setVoxel call: no material is ever used
+        if (!want_mat) return VX_OK;
+        g->mat_pending = true;
+        g->mat_values = mesh->values;
+        g->mat_first_use.assign(mesh->values.size(), -1);
+        g->mat_dtv = nullptr; g->mat_ntri = 0; g->mat_nids = 0;
+        VX_HIP(g->mattmp.ensure(mesh->values.size() * 2 + 256));
+        if (whole_build) return finish_materials(g, g->mat_first_use.data(), g->mat_first_use.size());
+        return VX_OK;
+    };
     g->triangles = te - tb;
     if (ntri == 0 || nvox == 0 || wb == we) {
         if (!mask_is_clear) VX_HIP(hipMemsetAsync(g->words.p, 0, mask_bytes, s));
-        g->has_materials = want_mat;
-        return VX_OK;
+        return no_calls_materials();
     }
 
     uint64_t U = 0;
@@ -844,7 +912,7 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
         VX_HIP(hipMemsetAsync(g->words.p, 0, mask_bytes, s));
         VX_TRY(setup_finish(ntri, g->ubase, g->btri, g->mail, s, &U));
     }
-    if (U == 0) { g->has_materials = want_mat; return VX_OK; }
+    if (U == 0) return no_calls_materials();
     uint32_t* umask = nullptr;
     if (g->kind == VX_GRID_VEC || want_mat) {
         VX_HIP(g->umask.ensure((size_t)(U + 1) * 4));
@@ -909,42 +977,34 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
     }
     if (want_mat) {
         // ---- per-voxel material ids (see k_mat_last): needs the word prefix (queued above for an unsharded build) and, for the Vec
-        // flavour, the hit bases; the order in which materials are first used is settled on the host from one byte per triangle
+        // flavour, the hit bases.  First half here: the last triangle per voxel of this shard and, per material value, the first
+        // triangle of this shard that uses it; second half (finish_materials) once the first uses of ALL shards are known -- at once
+        // for a whole build.
         bool pending = false;
         VX_TRY(prefix_launch(g, &pending));
         VX_TRY(prefix_finish(g, pending));
         const uint64_t nids = g->kind == VX_GRID_VEC ? g->vec_count : g->occupied;
-        const size_t tmp_bytes = (g->kind == VX_GRID_VEC ? 0 : (size_t)g->occupied * 4) + (size_t)ntri + 64 + mesh->values.size() * 2 + 64;
+        const size_t tmp_bytes = (g->kind == VX_GRID_VEC ? 0 : (size_t)nids * 4) + (size_t)ntri + 64 + mesh->values.size() * 2 + 64;
         VX_HIP(g->mattmp.ensure(tmp_bytes));
         uint8_t* base = g->mattmp.as<uint8_t>();
         uint32_t* last_tri = g->kind == VX_GRID_VEC ? nullptr : reinterpret_cast<uint32_t*>(base);
-        uint8_t* tri_hit = base + (g->kind == VX_GRID_VEC ? 0 : (size_t)g->occupied * 4);
-        int16_t* value_index = reinterpret_cast<int16_t*>(tri_hit + (((size_t)ntri + 63) & ~(size_t)63));
+        uint8_t* tri_hit = base + (g->kind == VX_GRID_VEC ? 0 : (size_t)nids * 4);
         VX_HIP(hipMemsetAsync(base, 0, (size_t)(tri_hit - base) + ntri, s));
         vx::launch_mat_last(g->recs.as<vx::TriRec>(), g->ubase.as<uint32_t>(), g->btri.as<uint32_t>(), ntri, g->g, umask, g->words.as<uint32_t>(),
                             g->wprefix.as<uint32_t>(), last_tri, tri_hit, s, xw);
         std::vector<uint8_t> hit(ntri);
         VX_HIP(hipMemcpyAsync(hit.data(), tri_hit, ntri, hipMemcpyDeviceToHost, s));
         VX_HIP(hipStreamSynchronize(s));
-        // addMatrialIfNeeded (voxelgrid.hpp:102-114): a value gets the next index when the first setVoxel call carrying it arrives
-        std::vector<int16_t> vindex(mesh->values.size(), (int16_t)-1);
+        g->mat_values = mesh->values;
+        g->mat_first_use.assign(mesh->values.size(), -1);
         const int32_t* tv = mesh->tri_value.data() + tb;
-        for (uint32_t t = 0; t < ntri; ++t) {
-            if (!hit[t] || vindex[(size_t)tv[t]] >= 0) continue;
-            vindex[(size_t)tv[t]] = (int16_t)g->materials.size();
-            g->materials.push_back(mesh->values[(size_t)tv[t]]);
-        }
-        VX_HIP(hipMemcpyAsync(value_index, vindex.data(), vindex.size() * 2, hipMemcpyHostToDevice, s));
-        VX_HIP(g->matids.ensure((size_t)nids * 2 + 16));
-        const int32_t* dtv = mesh->btv.as<int32_t>() + tb;
-        if (g->kind == VX_GRID_VEC)
-            vx::launch_mat_ids_calls(g->recs.as<vx::TriRec>(), g->ubase.as<uint32_t>(), g->btri.as<uint32_t>(), ntri, umask, g->hbase.as<uint32_t>(), dtv, value_index,
-                                     g->matids.as<int16_t>(), s);
-        else
-            vx::launch_mat_ids(last_tri, nids, dtv, value_index, g->matids.as<int16_t>(), s);
-        VX_HIP(hipStreamSynchronize(s));  // vindex lives on this stack frame
-        g->mat_count = nids;
-        g->has_materials = true;
+        for (uint32_t t = 0; t < ntri; ++t)
+            if (hit[t] && g->mat_first_use[(size_t)tv[t]] < 0) g->mat_first_use[(size_t)tv[t]] = (long long)(tb + t);
+        g->mat_dtv = mesh->btv.as<int32_t>() + tb;
+        g->mat_ntri = ntri;
+        g->mat_nids = nids;
+        g->mat_pending = true;
+        if (whole_build) VX_TRY(finish_materials(g, g->mat_first_use.data(), g->mat_first_use.size()));
     }
     VX_HIP(hipGetLastError());
     return VX_OK;
@@ -968,130 +1028,248 @@ vx_status vx_voxelize(const vx_mesh* mesh, float vs, vx_grid_kind kind, const vx
 }
 
 // ---- multi-GPU build inside one process -----------------------------------------------------------------------------
-vx_status vx_voxelize_multi(const vx_mesh* mesh, float vs, vx_grid_kind kind, int sat_variant, const int* devices, int nd, int all_gather, vx_grid** out)
+// vx_multi: the persistent form.  Created once per (mesh, device list): the mesh is uploaded to every device, every rank gets a
+// grid handle and a worker thread that lives as long as the context.  vx_multi_voxelize then runs with no upload, no allocation
+// (the grids' buffers are reused when sizes repeat) and no thread start: rank k voxelizes the word shard vx_shard_words(.., k, n)
+// that it derives from its own bounding-box pass (vx_voxelize_opts.shard_rank / shard_world: nobody needs the grid's word count
+// beforehand), the shards travel as peer copies, the destination grids rebuild word prefix and traversal structure.
+struct vx_multi {
+    int nd = 0;
+    vx_grid_kind kind = VX_GRID_BOOL;
+    std::vector<int> devices;
+    std::vector<vx_mesh*> meshes;
+    std::vector<vx_grid*> grids;
+    // workers
+    std::vector<std::thread> threads;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    uint64_t epoch = 0;       // bumped by vx_multi_voxelize: the workers' signal
+    int remaining = 0;        // workers still busy with the current epoch
+    bool quit = false;
+    float vs = 0.f;
+    vx_voxelize_opts opts{};
+    std::vector<vx_status> st;
+    std::vector<std::string> msg;
+};
+
+namespace {
+void multi_worker(vx_multi* m, int k)
+{
+    g_device = m->devices[(size_t)k];  // thread-local
+    uint64_t seen = 0;
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(m->mu);
+            m->cv_go.wait(lk, [&] { return m->quit || m->epoch != seen; });
+            if (m->quit) return;
+            seen = m->epoch;
+        }
+        vx_voxelize_opts o = m->opts;
+        o.shard_rank = k;
+        o.shard_world = m->nd;
+        o.word_begin = o.word_end = o.tri_begin = o.tri_end = 0;
+        const vx_status s = vx_voxelize_into(m->meshes[(size_t)k], m->vs, &o, m->grids[(size_t)k]);
+        m->st[(size_t)k] = s;
+        if (s != VX_OK) m->msg[(size_t)k] = g_err;
+        else {  // the shard must be complete before another device copies it
+            DeviceGuard dg(m->grids[(size_t)k]->device);
+            (void)hipStreamSynchronize(m->grids[(size_t)k]->stream);
+        }
+        {
+            std::lock_guard<std::mutex> lk(m->mu);
+            if (--m->remaining == 0) m->cv_done.notify_all();
+        }
+    }
+}
+}  // namespace
+
+vx_status vx_multi_create(const vx_mesh* mesh, const int* devices, int nd, vx_grid_kind kind, vx_multi** out)
 {
     if (!mesh || !devices || !out || nd < 1) return fail(VX_ERR_INVALID_ARG, "null argument");
     if (kind != VX_GRID_BOOL && kind != VX_GRID_AABBSTRUCT)
-        return fail(VX_ERR_UNSUPPORTED, "vx_voxelize_multi builds VX_GRID_BOOL / VX_GRID_AABBSTRUCT (VX_GRID_VEC's list order needs triangle shards)");
-    if (mesh->borrowed) return fail(VX_ERR_UNSUPPORTED, "vx_voxelize_multi needs a mesh with host arrays (vx_mesh_load_obj / vx_mesh_from_arrays)");
-    VX_TRY(check_voxel_size(vs));
+        return fail(VX_ERR_UNSUPPORTED, "multi-GPU builds are VX_GRID_BOOL / VX_GRID_AABBSTRUCT (VX_GRID_VEC's list order needs triangle shards)");
+    if (mesh->borrowed) return fail(VX_ERR_UNSUPPORTED, "multi-GPU builds need a mesh with host arrays (vx_mesh_load_obj / vx_mesh_from_arrays)");
     for (int k = 0; k < nd; ++k) VX_TRY(need_device(devices[k]));
+    vx_multi* m = new vx_multi();
+    m->nd = nd;
+    m->kind = kind;
+    m->devices.assign(devices, devices + nd);
+    m->meshes.assign((size_t)nd, nullptr);
+    m->grids.assign((size_t)nd, nullptr);
+    m->st.assign((size_t)nd, VX_OK);
+    m->msg.assign((size_t)nd, std::string());
     const int prev_device = g_device;
-    // Rank 0 first: its unsharded bbox pass fixes the grid (dims, word count) every shard refers to.  Then one host thread per
-    // rank: a build waits twice for counts from its device, and the ranks should wait side by side.
-    std::vector<vx_mesh*> meshes((size_t)nd, nullptr);
-    std::vector<vx_grid*> grids((size_t)nd, nullptr);
-    std::vector<vx_status> st((size_t)nd, VX_OK);
-    std::vector<std::string> msg((size_t)nd);
-    auto cleanup = [&](bool keep_outputs) {
-        for (int k = 0; k < nd; ++k) {
-            if (meshes[(size_t)k]) vx_mesh_free(meshes[(size_t)k]);
-            if (grids[(size_t)k] && !(keep_outputs && (k == 0 || all_gather))) vx_grid_free(grids[(size_t)k]);
-        }
-        g_device = prev_device;
-    };
-    uint64_t nwords = 0;
-    {
-        // the grid's extent from a bbox-only pass on devices[0] (a zero-triangle shard of the same vertex set)
-        g_device = devices[0];
-        vx_status s0 = vx_mesh_from_arrays(mesh->hv.data(), mesh->nv, mesh->hi.data(), mesh->nt, &meshes[0]);
-        if (s0 != VX_OK) { cleanup(false); return s0; }
-        vx_grid* probe = nullptr;
-        vx_voxelize_opts po{};
-        po.sat_variant = sat_variant;
-        po.tri_begin = 0; po.tri_end = 0; po.word_begin = 0; po.word_end = 0;
-        // (tri_begin == tri_end == 0 means "all triangles"; the probe instead voxelizes the empty word range below)
-        po.word_begin = 1; po.word_end = 1;
-        s0 = vx_voxelize(meshes[0], vs, kind, &po, &probe);
-        if (s0 == VX_ERR_INVALID_ARG) {  // a grid without words (flat mesh): build it plainly
-            s0 = vx_voxelize(meshes[0], vs, kind, nullptr, &probe);
-            if (s0 != VX_OK) { cleanup(false); return s0; }
-            grids[0] = probe;
-            out[0] = probe;
-            if (all_gather)
-                for (int k = 1; k < nd; ++k) {
-                    g_device = devices[k];
-                    s0 = vx_mesh_from_arrays(mesh->hv.data(), mesh->nv, mesh->hi.data(), mesh->nt, &meshes[(size_t)k]);
-                    if (s0 == VX_OK) s0 = vx_voxelize(meshes[(size_t)k], vs, kind, nullptr, &grids[(size_t)k]);
-                    if (s0 != VX_OK) { cleanup(false); return s0; }
-                    out[k] = grids[(size_t)k];
-                }
-            cleanup(true);
-            return VX_OK;
-        }
-        if (s0 != VX_OK) { cleanup(false); return s0; }
-        nwords = probe->g.nwords;
-        vx_grid_free(probe);
-    }
-    auto worker = [&](int k) {
-        g_device = devices[k];  // thread-local
-        vx_status s = VX_OK;
-        if (!meshes[(size_t)k]) s = vx_mesh_from_arrays(mesh->hv.data(), mesh->nv, mesh->hi.data(), mesh->nt, &meshes[(size_t)k]);
+    vx_status s = VX_OK;
+    for (int k = 0; k < nd && s == VX_OK; ++k) {
+        g_device = devices[k];
+        s = vx_mesh_from_arrays(mesh->hv.data(), mesh->nv, mesh->hi.data(), mesh->nt, &m->meshes[(size_t)k]);
+        if (s == VX_OK && !mesh->materials.empty())
+            s = vx_mesh_set_materials(m->meshes[(size_t)k], mesh->materials.data(), mesh->materials.size(), mesh->tri_mat.empty() ? nullptr : mesh->tri_mat.data());
+        if (s == VX_OK) s = mesh_to_device(m->meshes[(size_t)k]);
         if (s == VX_OK) {
-            vx_voxelize_opts o{};
-            o.sat_variant = sat_variant;
-            vx_shard_words(nwords, k, nd, &o.word_begin, &o.word_end, nullptr);
-            if (o.word_begin == o.word_end) { o.word_begin = o.word_end = (nwords ? 1 : 0); }  // an empty shard (more ranks than words)
-            s = vx_voxelize(meshes[(size_t)k], vs, kind, &o, &grids[(size_t)k]);
+            vx_grid* g = new vx_grid();
+            g->kind = kind;
+            g->set_dev(devices[k]);
+            m->grids[(size_t)k] = g;
         }
-        st[(size_t)k] = s;
-        if (s != VX_OK) msg[(size_t)k] = g_err;
-    };
-    {
-        std::vector<std::thread> th;
-        for (int k = 1; k < nd; ++k) th.emplace_back(worker, k);
-        worker(0);
-        for (auto& t : th) t.join();
+    }
+    g_device = prev_device;
+    if (s != VX_OK) { const std::string e = g_err; vx_multi_free(m); return fail(s, e); }
+    for (int k = 0; k < nd; ++k) m->threads.emplace_back(multi_worker, m, k);
+    *out = m;
+    return VX_OK;
+}
+
+vx_status vx_multi_voxelize(vx_multi* m, float vs, const vx_voxelize_opts* opts, int all_gather)
+{
+    if (!m) return fail(VX_ERR_INVALID_ARG, "null argument");
+    VX_TRY(check_voxel_size(vs));
+    vx_voxelize_opts o{};
+    if (opts) o = *opts;
+    if (o.word_begin || o.word_end || o.tri_begin || o.tri_end || o.shard_world) return fail(VX_ERR_INVALID_ARG, "vx_multi_voxelize shards the build itself");
+    const bool want_mat = (o.flags & VX_VOXELIZE_MATERIALS) != 0;
+    const int nd = m->nd;
+    for (int k = 0; k < nd; ++k)
+        if (!m->grids[(size_t)k]) return fail(VX_ERR_INVALID_ARG, "a grid of this context was handed to the caller (vx_multi_release_grid): create a new context");
+    {   // ---- every rank builds its shard, side by side
+        std::unique_lock<std::mutex> lk(m->mu);
+        m->vs = vs;
+        m->opts = o;
+        m->remaining = nd;
+        ++m->epoch;
+        m->cv_go.notify_all();
+        m->cv_done.wait(lk, [&] { return m->remaining == 0; });
     }
     for (int k = 0; k < nd; ++k)
-        if (st[(size_t)k] != VX_OK) { const vx_status s = st[(size_t)k]; const std::string m = msg[(size_t)k]; cleanup(false); return fail(s, m); }
+        if (m->st[(size_t)k] != VX_OK) return fail(m->st[(size_t)k], m->msg[(size_t)k]);
+    const uint64_t nwords = m->grids[0]->g.nwords;
+    for (int k = 1; k < nd; ++k)
+        if (m->grids[(size_t)k]->g.nwords != nwords) return fail(VX_ERR_HIP, "ranks disagree about the grid (different devices gave different bounding boxes?)");
     // ---- exchange: every destination pulls the other ranks' word ranges as peer copies (one slab per source device)
     const int ndst = all_gather ? nd : 1;
     hipError_t e = hipSuccess;
     for (int d = 0; d < ndst && e == hipSuccess; ++d) {
-        vx_grid* gd = grids[(size_t)d];
+        vx_grid* gd = m->grids[(size_t)d];
         DeviceGuard dg(gd->device);
         for (int k = 0; k < nd && e == hipSuccess; ++k) {
             if (k == d) continue;
-            if (grids[(size_t)k]->device != gd->device) {  // direct xGMI copies instead of staging through the host
+            vx_grid* gk = m->grids[(size_t)k];
+            if (gk->device != gd->device) {  // direct xGMI copies instead of staging through the host
                 int can = 0;
-                if (hipDeviceCanAccessPeer(&can, gd->device, grids[(size_t)k]->device) == hipSuccess && can) {
-                    const hipError_t pe = hipDeviceEnablePeerAccess(grids[(size_t)k]->device, 0);
-                    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
-                    else if (pe == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+                if (hipDeviceCanAccessPeer(&can, gd->device, gk->device) == hipSuccess && can) {
+                    (void)hipDeviceEnablePeerAccess(gk->device, 0);
+                    (void)hipGetLastError();  // (already enabled is not an error)
                 }
             }
             uint64_t wb = 0, we = 0;
             vx_shard_words(nwords, k, nd, &wb, &we, nullptr);
             if (we <= wb) continue;
-            vx_grid* gk = grids[(size_t)k];
-            (void)hipStreamSynchronize(gk->stream);  // the source shard is complete (its build ran on another host thread / stream)
             e = hipMemcpyPeerAsync(gd->words.as<uint32_t>() + wb, gd->device, gk->words.as<uint32_t>() + wb, gk->device, (size_t)(we - wb) * 4, gd->stream);
         }
     }
     for (int d = 0; d < ndst && e == hipSuccess; ++d) {
-        DeviceGuard dg(grids[(size_t)d]->device);
-        e = hipStreamSynchronize(grids[(size_t)d]->stream);
+        DeviceGuard dg(m->grids[(size_t)d]->device);
+        e = hipStreamSynchronize(m->grids[(size_t)d]->stream);
     }
-    if (e != hipSuccess) { cleanup(false); return fail(VX_ERR_HIP, std::string("peer exchange: ") + hipGetErrorString(e)); }
+    if (e != hipSuccess) return fail(VX_ERR_HIP, std::string("peer exchange: ") + hipGetErrorString(e));
+    // ---- materials: the index of a material is the order of its first use over ALL shards (vx_grid_finish_materials); the ids of the
+    // voxels in ascending order are the shards' id arrays one after the other
+    std::vector<uint64_t> shard_ids((size_t)nd, 0);
+    if (want_mat) {
+        const size_t nv = m->grids[0]->mat_first_use.size();
+        std::vector<long long> fu(nv, -1);
+        for (int k = 0; k < nd; ++k) {
+            const std::vector<long long>& a = m->grids[(size_t)k]->mat_first_use;
+            if (a.size() != nv) return fail(VX_ERR_HIP, "ranks disagree about the mesh's materials");
+            for (size_t v = 0; v < nv; ++v)
+                if (a[v] >= 0 && (fu[v] < 0 || a[v] < fu[v])) fu[v] = a[v];
+        }
+        for (int k = 0; k < nd; ++k) {
+            VX_TRY(finish_materials(m->grids[(size_t)k], fu.data(), fu.size()));
+            shard_ids[(size_t)k] = m->grids[(size_t)k]->mat_count;
+        }
+    }
     // ---- the complete masks: counts, word prefix and traversal structure; setVoxel calls of all shards add up
-    uint64_t calls = 0;
+    uint64_t calls = 0, total_ids = 0;
     for (int k = 0; k < nd; ++k) {
-        vx_grid_desc dsc;
-        (void)sync_counts(grids[(size_t)k]);
-        calls += grids[(size_t)k]->set_calls;
-        (void)dsc;
+        VX_TRY(sync_counts(m->grids[(size_t)k]));
+        calls += m->grids[(size_t)k]->set_calls;
+        total_ids += shard_ids[(size_t)k];
     }
+    const uint64_t ntri_all = m->meshes[0]->nt;
     for (int d = 0; d < ndst; ++d) {
-        vx_grid* gd = grids[(size_t)d];
+        vx_grid* gd = m->grids[(size_t)d];
+        DeviceGuard dg(gd->device);
+        if (want_mat && nd > 1) {
+            // gather the shards' ids in shard order (a destination's own ids move to their place first: a copy within the device)
+            DevBuf all;
+            all.dev = gd->device;
+            all.stream = gd->stream;
+            VX_HIP(all.ensure((size_t)total_ids * 2 + 16));
+            uint64_t off = 0;
+            for (int k = 0; k < nd; ++k) {
+                vx_grid* gk = m->grids[(size_t)k];
+                if (shard_ids[(size_t)k]) {
+                    if (gk->device == gd->device) VX_HIP(hipMemcpyAsync(all.as<int16_t>() + off, gk->matids.p, (size_t)shard_ids[(size_t)k] * 2, hipMemcpyDeviceToDevice, gd->stream));
+                    else VX_HIP(hipMemcpyPeerAsync(all.as<int16_t>() + off, gd->device, gk->matids.p, gk->device, (size_t)shard_ids[(size_t)k] * 2, gd->stream));
+                }
+                off += shard_ids[(size_t)k];
+            }
+            VX_HIP(hipStreamSynchronize(gd->stream));
+            gd->mattmp.release();   // (its first-half scratch is spent; every rank's own ids stay in its matids for the other destinations)
+            gd->mattmp = all;       // (kept so that the next build finds a block of this size)
+            gd->mat_gathered = true;
+            gd->mat_gather_count = total_ids;
+        }
         gd->set_calls = calls;
         gd->counts_valid = true;
-        gd->triangles = mesh->nt;
-        const vx_status s = vx_grid_refresh(gd);
-        if (s != VX_OK) { cleanup(false); return s; }
-        out[d] = gd;
+        gd->triangles = ntri_all;
+        VX_TRY(vx_grid_refresh(gd));
     }
-    cleanup(true);
+    return VX_OK;
+}
+
+vx_grid* vx_multi_grid(vx_multi* m, int k) { return (m && k >= 0 && k < m->nd) ? m->grids[(size_t)k] : nullptr; }
+
+vx_grid* vx_multi_release_grid(vx_multi* m, int k)
+{
+    if (!m || k < 0 || k >= m->nd) return nullptr;
+    vx_grid* g = m->grids[(size_t)k];
+    m->grids[(size_t)k] = nullptr;
+    return g;
+}
+
+void vx_multi_free(vx_multi* m)
+{
+    if (!m) return;
+    {
+        std::lock_guard<std::mutex> lk(m->mu);
+        m->quit = true;
+        m->cv_go.notify_all();
+    }
+    for (auto& t : m->threads) t.join();
+    const int prev_device = g_device;
+    for (int k = 0; k < m->nd; ++k) {
+        if (m->grids[(size_t)k]) vx_grid_free(m->grids[(size_t)k]);
+        if (m->meshes[(size_t)k]) vx_mesh_free(m->meshes[(size_t)k]);
+    }
+    g_device = prev_device;
+    delete m;
+}
+
+// one-shot form: create the context, build once, hand the destination grids to the caller
+vx_status vx_voxelize_multi(const vx_mesh* mesh, float vs, vx_grid_kind kind, int sat_variant, const int* devices, int nd, int all_gather, vx_grid** out)
+{
+    if (!out) return fail(VX_ERR_INVALID_ARG, "null argument");
+    vx_multi* m = nullptr;
+    VX_TRY(vx_multi_create(mesh, devices, nd, kind, &m));
+    vx_voxelize_opts o{};
+    o.sat_variant = sat_variant;
+    const vx_status s = vx_multi_voxelize(m, vs, &o, all_gather);
+    if (s != VX_OK) { const std::string e = g_err; vx_multi_free(m); return fail(s, e); }
+    const int ndst = all_gather ? nd : 1;
+    for (int d = 0; d < ndst; ++d) out[d] = vx_multi_release_grid(m, d);
+    vx_multi_free(m);
     return VX_OK;
 }
 
@@ -1317,17 +1495,41 @@ vx_status vx_grid_materials(const vx_grid* g, vx_material* out, uint64_t cap, ui
 vx_status vx_grid_material_ids(const vx_grid* g, int16_t* out, uint64_t cap, uint64_t* count)
 {
     if (!g || (!out && cap)) return fail(VX_ERR_INVALID_ARG, "null argument");
-    const uint64_t n = g->has_materials ? g->mat_count : 0;
+    const uint64_t n = g->has_materials ? (g->mat_gathered ? g->mat_gather_count : g->mat_count) : 0;
     if (count) *count = n;
     const uint64_t m = cap < n ? cap : n;
     if (!m) return VX_OK;
     DeviceGuard dg(g->device);
-    VX_HIP(hipMemcpyAsync(out, g->matids.p, (size_t)m * 2, hipMemcpyDeviceToHost, g->stream));
+    VX_HIP(hipMemcpyAsync(out, g->mat_gathered ? g->mattmp.p : g->matids.p, (size_t)m * 2, hipMemcpyDeviceToHost, g->stream));
     VX_HIP(hipStreamSynchronize(g->stream));
     return VX_OK;
 }
 
-const int16_t* vx_grid_material_ids_device(const vx_grid* g) { return (g && g->has_materials && g->mat_count) ? g->matids.as<int16_t>() : nullptr; }
+vx_status vx_grid_material_first_use(const vx_grid* g, int64_t* out, uint64_t cap, uint64_t* count)
+{
+    if (!g || (!out && cap)) return fail(VX_ERR_INVALID_ARG, "null argument");
+    if (!g->mat_pending && !g->has_materials) return fail(VX_ERR_INVALID_ARG, "the grid was not built with VX_VOXELIZE_MATERIALS");
+    const uint64_t n = g->mat_first_use.size();
+    if (count) *count = n;
+    const uint64_t m = cap < n ? cap : n;
+    for (uint64_t i = 0; i < m; ++i) out[i] = (int64_t)g->mat_first_use[i];
+    return VX_OK;
+}
+
+vx_status vx_grid_finish_materials(vx_grid* g, const int64_t* first_use_min, uint64_t count)
+{
+    if (!g || (!first_use_min && count)) return fail(VX_ERR_INVALID_ARG, "null argument");
+    if (!g->mat_pending) return g->has_materials ? VX_OK : fail(VX_ERR_INVALID_ARG, "the grid was not built with VX_VOXELIZE_MATERIALS");
+    std::vector<long long> fu(first_use_min, first_use_min + count);
+    return finish_materials(g, fu.data(), fu.size());
+}
+
+const int16_t* vx_grid_material_ids_device(const vx_grid* g)
+{
+    if (!g || !g->has_materials) return nullptr;
+    if (g->mat_gathered) return g->mat_gather_count ? g->mattmp.as<int16_t>() : nullptr;
+    return g->mat_count ? g->matids.as<int16_t>() : nullptr;
+}
 
 void vx_grid_free(vx_grid* g)
 {

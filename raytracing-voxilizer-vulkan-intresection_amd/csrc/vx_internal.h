@@ -63,7 +63,8 @@ void launch_tri_setup(const float* verts, const int32_t* idx, uint64_t tri_begin
                       int sat_variant, uint32_t zlo, uint32_t zhi, TriRec* recs, uint32_t* units, hipStream_t s, const DevGrid* dgrid = nullptr,
                       void* clear = nullptr /*optional: a 16-byte aligned buffer the kernel zeroes beside its own work*/, uint64_t clear_bytes = 0,
                       uint64_t shard_wb = 0, uint64_t shard_we = 0 /*with dgrid: derive zlo / zhi on the device from the word shard (0, 0: whole grid)*/,
-                      uint32_t* ext = nullptr /*optional, ntri words: bits 16..20 of the range values, for grids with an axis above 65535 cells*/);
+                      uint32_t* ext = nullptr /*optional, ntri words: bits 16..20 of the range values, for grids with an axis above 65535 cells*/,
+                      uint32_t shard_rank = 0, uint32_t shard_world = 0 /*with dgrid and world > 1: the word shard vx_shard_words gives that rank*/);
 
 // exclusive scan of n uint32 (or of their popcounts) into out[0..n] (out[n] = total, saturating check via *total64)
 size_t scan_tmp_bytes(uint64_t n);

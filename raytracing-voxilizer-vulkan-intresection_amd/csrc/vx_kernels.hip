@@ -497,7 +497,8 @@ __global__ __launch_bounds__(256) void k_tri_setup(const float* __restrict__ ver
                                                    TriRec* __restrict__ recs, uint32_t* __restrict__ units, const DevGrid* __restrict__ dgrid,
                                                    uint4* __restrict__ clear /*optional: 16-byte pieces to zero*/, uint64_t clear_n,
                                                    uint64_t shard_wb, uint64_t shard_we /*with dgrid: the bitmask words of a sharded build (0, 0: all)*/,
-                                                   uint32_t* __restrict__ ext /*bits 16..20 of the six range values (grids with an axis above 65535 cells)*/)
+                                                   uint32_t* __restrict__ ext /*bits 16..20 of the six range values (grids with an axis above 65535 cells)*/,
+                                                   uint32_t shard_rank, uint32_t shard_world /*with dgrid, world > 1: the word shard of that rank*/)
 {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     // (optional) the build's bitmask is cleared by this kernel's threads, beside their own work: a launch and its gap less
@@ -508,6 +509,14 @@ __global__ __launch_bounds__(256) void k_tri_setup(const float* __restrict__ ver
         for (int a = 0; a < 3; ++a) { g.org[a] = dgrid->org[a]; g.dim[a] = dgrid->dim[a]; }
         zlo = 0u;
         zhi = g.dim[2];
+        if (shard_world > 1u) {  // word shard by rank: vx_shard_words on the device-side dims (the host redoes it once it has seen the bbox)
+            const uint64_t nw = ((uint64_t)g.dim[0] * g.dim[1] * g.dim[2] + 31ull) / 32ull;
+            const uint64_t chunk = (nw + shard_world - 1u) / shard_world;
+            shard_wb = (uint64_t)shard_rank * chunk;
+            if (shard_wb > nw) shard_wb = nw;
+            shard_we = shard_wb + chunk > nw ? nw : shard_wb + chunk;
+            if (shard_we == shard_wb) { zlo = zhi = 0u; shard_we = 0; }  // an empty shard (more ranks than words)
+        }
         if (shard_we) {  // the z slab that holds the voxels of words [shard_wb, shard_we): the host's own arithmetic (vx_voxelize_into)
             const uint64_t XY = (uint64_t)g.dim[0] * g.dim[1];
             if (XY) {
@@ -558,13 +567,13 @@ __global__ __launch_bounds__(256) void k_tri_setup(const float* __restrict__ ver
 
 void launch_tri_setup(const float* verts, const int32_t* idx, uint64_t tri_begin, uint32_t ntri, const GridParams& g, int sat_variant,
                       uint32_t zlo, uint32_t zhi, TriRec* recs, uint32_t* units, hipStream_t s, const DevGrid* dgrid, void* clear, uint64_t clear_bytes, uint64_t shard_wb, uint64_t shard_we,
-                      uint32_t* ext)
+                      uint32_t* ext, uint32_t shard_rank, uint32_t shard_world)
 {
     if (!ntri) return;
     // serial driver: voxelSize = halfVoxelSize.x * 2.0f (VoxelBuilder.hpp:173); threaded driver: vSize = voxelSize (:500)
     const float vsize = sat_variant == 0 ? g.half * 2.0f : g.vs;
     VX_KL(k_tri_setup, dim3((ntri + 255) / 256), dim3(256), 0, s, verts, idx, tri_begin, ntri, g, vsize, zlo, zhi, recs, units, dgrid,
-          reinterpret_cast<uint4*>(clear), clear ? clear_bytes / 16 : 0, shard_wb, shard_we, ext);
+          reinterpret_cast<uint4*>(clear), clear ? clear_bytes / 16 : 0, shard_wb, shard_we, ext, shard_rank, shard_world);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1110,7 +1119,9 @@ __global__ __launch_bounds__(256) void k_mat_last(const TriRec* __restrict__ rec
             mask &= mask - 1;
             const uint64_t i = row + w.xseg + b;
             const uint64_t wi = i >> 5;
-            const uint32_t rank = word_prefix[wi] + __popc(words[wi] & ((1u << (i & 31u)) - 1u));
+            const uint32_t wd = words[wi];
+            if (!((wd >> (i & 31u)) & 1u)) continue;  // a voxel of the z slab outside this build's word shard: not in this mask, not ranked here
+            const uint32_t rank = word_prefix[wi] + __popc(wd & ((1u << (i & 31u)) - 1u));
             atomicMax(&last_tri[rank], t + 1u);
         }
     });

@@ -33,7 +33,7 @@ class GridDesc(C.Structure):
 
 class VoxelizeOpts(C.Structure):
     _fields_ = [("sat_variant", C.c_int32), ("flags", C.c_int32), ("word_begin", C.c_uint64), ("word_end", C.c_uint64),
-                ("tri_begin", C.c_uint64), ("tri_end", C.c_uint64), ("stream", C.c_void_p)]
+                ("tri_begin", C.c_uint64), ("tri_end", C.c_uint64), ("stream", C.c_void_p), ("shard_rank", C.c_int32), ("shard_world", C.c_int32)]
 
 
 class TraceArgs(C.Structure):
@@ -59,7 +59,8 @@ SYMBOLS = [
     "vx_voxelize", "vx_voxelize_into", "vx_voxelize_multi",
     "vx_grid_create", "vx_grid_describe", "vx_grid_set_voxel", "vx_grid_test_voxel", "vx_grid_coords", "vx_grid_bytes",
     "vx_grid_bitmask", "vx_grid_bitmask_device", "vx_grid_bitmask_device_mut", "vx_grid_refresh", "vx_grid_aabbs",
-    "vx_grid_aabbs_device", "vx_grid_bind_aabbs_device", "vx_grid_materials", "vx_grid_material_ids", "vx_grid_material_ids_device", "vx_grid_free",
+    "vx_grid_aabbs_device", "vx_grid_bind_aabbs_device", "vx_grid_materials", "vx_grid_material_ids", "vx_grid_material_ids_device", "vx_grid_material_first_use",
+    "vx_grid_finish_materials", "vx_multi_create", "vx_multi_voxelize", "vx_multi_grid", "vx_multi_release_grid", "vx_multi_free", "vx_grid_free",
     "vx_octree_build", "vx_octree_num_items", "vx_octree_num_nodes", "vx_octree_bytes", "vx_octree_items", "vx_octree_nodes",
     "vx_octree_root_bounds", "vx_octree_aabbs", "vx_octree_aabbs_device", "vx_octree_free",
     "vx_trace", "vx_trace_device", "vx_trace_primary_device", "vx_trace_ex", "vx_trace_ex_device",
@@ -131,6 +132,16 @@ def lib():
     L.vx_voxelize.argtypes = [vp, C.c_float, C.c_int, C.POINTER(VoxelizeOpts), C.POINTER(vp)]
     L.vx_voxelize_into.argtypes = [vp, C.c_float, C.POINTER(VoxelizeOpts), vp]
     L.vx_voxelize_multi.argtypes = [vp, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(vp)]
+    L.vx_multi_create.argtypes = [vp, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(vp)]
+    L.vx_multi_voxelize.argtypes = [vp, C.c_float, vp, C.c_int]
+    L.vx_multi_grid.argtypes = [vp, C.c_int]
+    L.vx_multi_grid.restype = vp
+    L.vx_multi_release_grid.argtypes = [vp, C.c_int]
+    L.vx_multi_release_grid.restype = vp
+    L.vx_multi_free.argtypes = [vp]
+    L.vx_multi_free.restype = None
+    L.vx_grid_material_first_use.argtypes = [vp, C.POINTER(C.c_int64), C.c_uint64, C.POINTER(C.c_uint64)]
+    L.vx_grid_finish_materials.argtypes = [vp, C.POINTER(C.c_int64), C.c_uint64]
     L.vx_grid_create.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_float, fp, vp, C.POINTER(vp)]
     L.vx_grid_describe.argtypes = [vp, C.POINTER(GridDesc)]
     L.vx_grid_set_voxel.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64]
@@ -306,15 +317,19 @@ class Mesh:
 
 class Grid:
     """vx_grid handle (a VoxelGridBool / VoxelGridAABBstruct / VoxelGridVec)."""
+    owned = True
+
 
     def __init__(self, handle):
         self.h = handle
 
     @classmethod
-    def voxelize(cls, mesh, voxel_size, kind=GRID_BOOL, sat_variant=0, words=None, tris=None, stream=None, materials=False):
+    def voxelize(cls, mesh, voxel_size, kind=GRID_BOOL, sat_variant=0, words=None, tris=None, stream=None, materials=False, shard=None):
         o = VoxelizeOpts()
         o.sat_variant = sat_variant
         o.flags = VOXELIZE_MATERIALS if materials else 0
+        if shard is not None:
+            o.shard_rank, o.shard_world = shard
         if words is not None:
             o.word_begin, o.word_end = words
         if tris is not None:
@@ -333,10 +348,12 @@ class Grid:
         _check(lib().vx_voxelize_multi(mesh.h, np.float32(voxel_size), kind, sat_variant, dv, len(devices), 1 if all_gather else 0, hs))
         return [cls(C.c_void_p(hs[i])) for i in range(n)]
 
-    def revoxelize(self, mesh, voxel_size, sat_variant=0, words=None, tris=None, stream=None, materials=False):
+    def revoxelize(self, mesh, voxel_size, sat_variant=0, words=None, tris=None, stream=None, materials=False, shard=None):
         o = VoxelizeOpts()
         o.sat_variant = sat_variant
         o.flags = VOXELIZE_MATERIALS if materials else 0
+        if shard is not None:
+            o.shard_rank, o.shard_world = shard
         if words is not None:
             o.word_begin, o.word_end = words
         if tris is not None:
@@ -394,6 +411,18 @@ class Grid:
         if n.value:
             _check(lib().vx_grid_aabbs(self.h, out.ctypes.data, n.value, C.byref(n)))
         return out
+
+    def material_first_use(self):
+        """Sharded VX_VOXELIZE_MATERIALS build: per material value the first triangle of this shard that uses it (-1: none)."""
+        n = C.c_uint64()
+        _check(lib().vx_grid_material_first_use(self.h, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), dtype=np.int64)
+        _check(lib().vx_grid_material_first_use(self.h, out.ctypes.data_as(C.POINTER(C.c_int64)), n.value, None))
+        return out[:n.value]
+
+    def finish_materials(self, first_use_min):
+        fu = np.ascontiguousarray(first_use_min, dtype=np.int64)
+        _check(lib().vx_grid_finish_materials(self.h, fu.ctypes.data_as(C.POINTER(C.c_int64)), fu.size))
 
     def materials(self):
         """(getMatrials() as MATERIAL records, getMatIdx() as int16[]) -- empty unless built with materials=True."""
@@ -466,8 +495,43 @@ class Grid:
         _check(lib().vx_trace_primary_device(self.h, vi, pi, width, height, np.float32(tmin), np.float32(tmax), t_ptr, prim_ptr))
 
     def free(self):
-        if self.h:
+        if self.h and self.owned:
             lib().vx_grid_free(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class BorrowedGrid(Grid):
+    """A grid owned by a vx_multi context (valid until its next voxelize / free)."""
+    owned = False
+
+
+class Multi:
+    """vx_multi handle: a mesh resident on several devices (logical ranks allowed), one grid and one worker thread per rank;
+    voxelize() rebuilds the grid in steady state (word shards by rank + peer copies)."""
+
+    def __init__(self, mesh, devices, kind=GRID_BOOL):
+        dv = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        _check(lib().vx_multi_create(mesh.h, dv, len(devices), kind, C.byref(h)))
+        self.h = h
+        self.n = len(devices)
+
+    def voxelize(self, voxel_size, sat_variant=0, materials=False, all_gather=False):
+        o = VoxelizeOpts()
+        o.sat_variant = sat_variant
+        o.flags = VOXELIZE_MATERIALS if materials else 0
+        _check(lib().vx_multi_voxelize(self.h, np.float32(voxel_size), C.byref(o), 1 if all_gather else 0))
+        return [BorrowedGrid(C.c_void_p(lib().vx_multi_grid(self.h, k))) for k in range(self.n if all_gather else 1)]
+
+    def free(self):
+        if self.h:
+            lib().vx_multi_free(self.h)
             self.h = None
 
     def __del__(self):

@@ -744,8 +744,83 @@ def test_material_ids(gpu, name, vs, nmat, seed):
     g = gpu.Grid.voxelize(plain, vs, materials=True)
     mats, mid = g.materials()
     assert (len(mats) == 1 and not mid.any() and len(mid) == g.describe()["occupied"]) or g.describe()["occupied"] == 0
-    with pytest.raises(gpu.VxError):
-        gpu.Grid.voxelize(mesh, vs, words=(0, 1), materials=True)
+
+
+@pytest.mark.parametrize("name,vs,nmat,seed,nranks", [("adversarial", 0.0625, 5, 3, 3), ("soup2000", 0.02, 6, 4, 2), ("blob70k", 2.0 / 64, 4, 5, 8)])
+def test_material_ids_sharded(gpu, name, vs, nmat, seed, nranks):
+    """VX_VOXELIZE_MATERIALS on shards (SURVEY 8(e) + 8(f)2): word shards by rank (Bool) and triangle shards (Vec).  A shard knows the
+    last triangle per voxel of its own slab, but the index of a material is the order of its first use over the WHOLE build
+    (voxelgrid.hpp:102-114): the shards report their first uses, the element-wise minimum finishes every shard, and the shards' id
+    arrays in shard order are the unsharded build's getMatIdx()."""
+    v, t, recs, ids = _material_scene(name, nmat, seed)
+    vs = np.float32(vs)
+    mesh = gpu.Mesh.from_arrays(v, t)
+    mesh.set_materials(recs, ids)
+    tv, nvalues, values = _value_ids(recs, ids)
+    whole = gpu.Grid.voxelize(mesh, vs, gpu.GRID_BOOL, materials=True)
+    wm, wid = whole.materials()
+    oids, order = oracle.material_ids(v, t, vs, tv, nvalues)
+    assert np.array_equal(wid, oids)
+    # ---- word shards by rank
+    shards = [gpu.Grid.voxelize(mesh, vs, gpu.GRID_BOOL, materials=True, shard=(k, nranks)) for k in range(nranks)]
+    assert all(len(s.materials()[1]) == 0 for s in shards)          # pending: nothing is reported before the finish
+    fu = np.stack([s.material_first_use() for s in shards])
+    fmin = np.where((fu >= 0).any(0), np.where(fu >= 0, fu, np.iinfo(np.int64).max).min(0), -1)
+    assert np.array_equal(fmin, whole.material_first_use())
+    for s in shards:
+        s.finish_materials(fmin)
+    assert np.array_equal(np.concatenate([s.materials()[1] for s in shards]), oids)
+    for s in shards:
+        assert s.materials()[0].tobytes() == wm.tobytes()
+    acc = np.zeros_like(whole.bitmask())
+    for s in shards:
+        acc |= s.bitmask()
+    assert np.array_equal(acc, whole.bitmask())
+    # ---- triangle shards (Vec: one id per setVoxel call, call order)
+    wv = gpu.Grid.voxelize(mesh, vs, gpu.GRID_VEC, materials=True)
+    ovids, vorder = oracle.material_ids(v, t, vs, tv, nvalues, per_call=True, ncalls=wv.describe()["set_calls"])
+    assert np.array_equal(wv.materials()[1], ovids)
+    T = len(t)
+    cuts = [T * k // nranks for k in range(nranks + 1)]
+    tsh = [gpu.Grid.voxelize(mesh, vs, gpu.GRID_VEC, materials=True, tris=(cuts[k], cuts[k + 1])) for k in range(nranks) if cuts[k + 1] > cuts[k]]
+    fu = np.stack([s.material_first_use() for s in tsh])
+    fmin = np.where((fu >= 0).any(0), np.where(fu >= 0, fu, np.iinfo(np.int64).max).min(0), -1)
+    for s in tsh:
+        s.finish_materials(fmin)
+    assert np.array_equal(np.concatenate([s.materials()[1] for s in tsh]), ovids)
+    assert tsh[0].materials()[0].tobytes() == wv.materials()[0].tobytes()
+
+
+def test_multi_context_steady_state(gpu):
+    """vx_multi: the mesh resident on every rank's device, persistent grids and worker threads; rebuilds at changing
+    voxel sizes, with and without materials, to one destination or all -- each equal to the single-GPU build and the oracle."""
+    v, t, recs, ids = _material_scene("blob70k", 4, 5)
+    mesh = gpu.Mesh.from_arrays(v, t)
+    mesh.set_materials(recs, ids)
+    tv, nvalues, values = _value_ids(recs, ids)
+    mc = gpu.Multi(mesh, [0] * 4)
+    for rep, (vs, mats, allg, sat) in enumerate([(2.0 / 64, False, False, 0), (2.0 / 128, True, False, 1), (2.0 / 64, True, True, 0), (2.0 / 96, False, True, 0),
+                                                  (2.0 / 128, True, False, 0)]):
+        vs = np.float32(vs)
+        gs = mc.voxelize(vs, sat_variant=sat, materials=mats, all_gather=allg)
+        assert len(gs) == (4 if allg else 1)
+        ow, calls, gi = oracle.build_bool(v, t, vs, threads=0 if sat == 0 else 2)
+        oa = oracle.bool_aabbs(ow, gi, vs)
+        for g in gs:
+            d = g.describe()
+            assert d["dim"] == gi["dim"] and d["set_calls"] == calls and d["occupied"] == len(oa)
+            assert np.array_equal(g.bitmask(), ow) and g.aabbs().tobytes() == oa.tobytes()
+            if mats:
+                oids, order = oracle.material_ids(v, t, vs, tv, nvalues, sat=sat)
+                gm, gid = g.materials()
+                assert np.array_equal(gid, oids) and len(gm) == len(order)
+            else:
+                assert len(g.materials()[1]) == 0
+        rays = vx_scenes.random_rays(2000, gi["bmin"], gi["bmax"], seed=20 + rep)
+        tt, pp, _ = gs[-1].trace(rays)
+        ot, op = oracle.trace_brute(oa, rays)
+        assert np.array_equal(tt, ot) and np.array_equal(pp, op)
+    mc.free()
 
 
 # ---------------------------------------------------------------------------------------------- multi-GPU entry of the C ABI
