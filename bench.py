@@ -45,7 +45,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 VALU_ISSUE_PEAK = 1.2288e12  # wave64 VALU instructions/s: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction
-PROFILE_TAGS = ("r2", "r1")  # profiles/<tag>_traffic.json / _issue.json, newest first
+PROFILE_TAGS = ("r3", "r2", "r1")  # profiles/<tag>_traffic.json / _issue.json, newest first
 
 
 def parse():

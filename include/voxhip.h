@@ -133,8 +133,8 @@ void vx_mesh_free(vx_mesh* m);
  * Limits (the reference has none besides memory): at most 2^21 cells per axis -- the bound the reference's own Octree has
  * (octTree.hpp:583-585); the per-triangle candidate ranges are 16 + 16 bits in the triangle record plus 5 + 5 high bits in an
  * extension word read only by grids with an axis above 65535 cells -- and 2^37 cells in total.  Beyond either vx_voxelize fails with
- * VX_ERR_CAPACITY, vx_octree_build with VX_ERR_MORTON_BITS and the reference's message.  Rays (vx_trace*) need every axis to have
- * at most 65535 cells (VX_ERR_UNSUPPORTED beyond: the walk packs two cell coordinates into one register). */
+ * VX_ERR_CAPACITY, vx_octree_build with VX_ERR_MORTON_BITS and the reference's message.  Rays (vx_trace*) work on every grid the
+ * builds accept (grids with an axis above 65535 cells are walked by variants of the ray kernel that keep 32-bit cell coordinates). */
 vx_status vx_voxelize(const vx_mesh* mesh, float voxel_size, vx_grid_kind kind, const vx_voxelize_opts* opts /*NULL ok*/,
                       vx_grid** out);
 /* same, re-using an existing grid handle's device buffers (steady-state loops; no allocation when sizes repeat) */

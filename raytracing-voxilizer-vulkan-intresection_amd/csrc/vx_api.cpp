@@ -1542,8 +1542,6 @@ void vx_grid_free(vx_grid* g)
 // ---- rays -----------------------------------------------------------------------------------------------------
 static vx_status trace_common(vx_grid* g, vx::TraceIO io)
 {
-    if (g->g.dim[0] > 65535u || g->g.dim[1] > 65535u || g->g.dim[2] > 65535u)
-        return fail(VX_ERR_UNSUPPORTED, "rays need a grid of at most 65535 cells per axis (the walk packs two cell coordinates into one register)");
     VX_TRY(ensure_coarse(g));
     const uint32_t* prefix = nullptr;
     void* idx_tmp = nullptr;

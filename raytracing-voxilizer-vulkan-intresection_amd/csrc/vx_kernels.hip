@@ -873,6 +873,10 @@ __global__ __launch_bounds__(256) void k_voxelize(const TriRec* __restrict__ rec
             // memory side and drop the line from L2 instead of updating it, nothing else writes the mask in this kernel, and
             // what older kernels left in the caches (the previous build's mask) is invalidated at the kernel boundary like every
             // other buffer this pipeline passes from kernel to kernel.  A stale copy can only show fewer bits: one request more.
+            // A mask written from OUTSIDE the library between two builds (vx_grid_bitmask_device_mut: the RCCL all-gather / the peer
+            // copies of a multi-rank exchange) is covered the same way: every build clears its mask first -- k_tri_setup's threads or
+            // a memset, both kernels in front of this one on the stream -- so the loads here only ever see this build's own bits
+            // (tests/test_gpu_parity.py::test_rebuild_after_external_write_of_the_mask).
             if (lo && wi >= wb && wi < we) { if ((words[wi] & lo) != lo) { atomicOr(&words[wi], lo); VX_V_SENT } hits += __popc(lo); }        // voxelgridBool.cpp:66
             if (hi && wi + 1 >= wb && wi + 1 < we) { if ((words[wi + 1] & hi) != hi) { atomicOr(&words[wi + 1], hi); VX_V_SENT } hits += __popc(hi); }
 #endif

@@ -86,8 +86,18 @@ __global__ __launch_bounds__(256) void k_build_bricks3(const uint32_t* __restric
         const uint64_t q = grp / chunks_x;
         const uint32_t by = (uint32_t)(q % BY), bz = (uint32_t)(q / BY);
         const uint32_t x0 = cx * 512u;
-        // ---- load: 64 rows x 16 words, four items per thread
+        // ---- load: 64 rows x 16 words.  Rows of a multiple of 128 voxels start on 16-byte boundaries: one 16-byte load per thread
+        // (four words of one row) instead of four 4-byte loads with funnel shifts -- the kernel is bound by the latency of these
+        // strided loads, not by their bytes.
         uint32_t nonzero = 0u;
+        if ((X & 127u) == 0u) {
+            const uint32_t r = threadIdx.x >> 2, q4 = (threadIdx.x & 3u) * 4u;
+            const uint32_t z = bz * 8u + (r >> 3), y = by * 8u + (r & 7u), xs = x0 + q4 * 32u;
+            uint4 val = make_uint4(0u, 0u, 0u, 0u);
+            if (z < Z && y < Y && xs < X) val = *reinterpret_cast<const uint4*>(words + (((uint64_t)X * ((uint64_t)y + (uint64_t)Y * z) + xs) >> 5));
+            rows[r][q4] = val.x; rows[r][q4 + 1u] = val.y; rows[r][q4 + 2u] = val.z; rows[r][q4 + 3u] = val.w;
+            nonzero = val.x | val.y | val.z | val.w;
+        } else
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t item = (uint32_t)k * 256u + threadIdx.x;
@@ -201,7 +211,20 @@ namespace {
 // Everything a lane carries for the ray it is currently tracing, in PERMUTED axis order: w = the major axis, u and v the axes
 // after it cyclically.  hitAabb (rint:46-56) is a max of per-axis minima and a min of per-axis maxima, so evaluating it in
 // (u, v, w) order yields the same float as in (x, y, z) order; only the voxel index of a hit needs the real order.
-template <typename IdxT>
+// Two cell (or brick) coordinates in one register: 16 + 16 bits -- every grid whose axes have at most 65535 cells -- or, WIDE, 32 + 32
+// bits (grids with an axis of up to 2^21 cells; the reference's dims are size_t, VoxelBuilder.hpp:347-349).  The wide form costs four
+// registers and is compiled only into the variants that walk such grids.
+template <bool WIDE> struct Pk { typedef uint32_t T; };
+template <> struct Pk<true> { typedef unsigned long long T; };
+template <bool WIDE> __device__ __forceinline__ typename Pk<WIDE>::T pk_make(int lo, int hi)
+{
+    typedef typename Pk<WIDE>::T T;
+    return WIDE ? (T)((T)(uint32_t)lo | ((T)(uint32_t)hi << (WIDE ? 32 : 16))) : (T)((uint32_t)lo | ((uint32_t)hi << 16));
+}
+template <bool WIDE> __device__ __forceinline__ int pk_lo(typename Pk<WIDE>::T v) { return WIDE ? (int)(uint32_t)v : (int)((uint32_t)v & 0xFFFFu); }
+template <bool WIDE> __device__ __forceinline__ int pk_hi(typename Pk<WIDE>::T v) { return WIDE ? (int)(uint32_t)((unsigned long long)v >> 32) : (int)((uint32_t)v >> 16); }
+
+template <typename IdxT, bool WIDE = false>
 struct WalkLane {
     float ou, ov, ow;        // origin
     float du, dv;            // direction (the major component is only needed through its reciprocal)
@@ -217,10 +240,11 @@ struct WalkLane {
     int lvl, k;              // current slab: level (2 block slabs, 1 brick slabs; 0: inside a brick of brick slab k) and its index along w
     int cw0;                 // cell index along w where this ray (or piece) starts, one cell of slack: slabs wholly in front of it are never looked at
     // occupied bricks of the current brick slab's rectangle, waiting for the brick phase
-    uint32_t pend;           // bits 0..15: brick jb + j = (cu0 + (jb + j) % nu, cv0 + (jb + j) / nu) is occupied; bits 16..30: nu; bit 31: more windows
+    uint32_t pend;           // bits 0..15: brick jb + j = (cu0 + (jb + j) % nu, cv0 + (jb + j) / nu) is occupied; bits 16..30: nu (WIDE: in nu_w); bit 31: more windows
     int jb;                  // first rectangle cell of the current 16-cell window (0 unless the rectangle has more than 16 cells)
-    uint32_t pc;             // cu0 | cv0 << 16
-    uint32_t pu, pv;         // the slab's cell rectangle: u0 | u1 << 16, v0 | v1 << 16
+    typename Pk<WIDE>::T pc;      // cu0 | cv0 << 16 (WIDE: << 32)
+    typename Pk<WIDE>::T pu, pv;  // the slab's cell rectangle: u0 | u1 << 16, v0 | v1 << 16
+    int nu_w;                // WIDE only: the rectangle's width in bricks (does not fit 15 bits)
     // level 0: the brick being walked -- its eight slab words (one 64-byte line) and the slabs still to look at
     unsigned long long w0, w1, w2, w3, w4, w5, w6, w7;
     uint32_t sm;             // bit s: slab s of the brick may hold a cell the ray touches (word & brick-level rectangle != 0)
@@ -279,8 +303,8 @@ __device__ __forceinline__ void load_ray_w(bool primary, uint64_t r, const float
 }
 
 // Ray set-up: major axis, tolerance, grid clip, first slab.  Returns false when the ray cannot touch the grid.
-template <typename IdxT>
-__device__ __forceinline__ bool walk_setup(WalkLane<IdxT>& R, const GridParams& g, float inv_vs, float tmax, float ox, float oy, float oz, float dx, float dy,
+template <typename IdxT, bool WIDE>
+__device__ __forceinline__ bool walk_setup(WalkLane<IdxT, WIDE>& R, const GridParams& g, float inv_vs, float tmax, float ox, float oy, float oz, float dx, float dy,
                                            float dz)
 {
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;  // rint:48
@@ -333,6 +357,7 @@ __device__ __forceinline__ bool walk_setup(WalkLane<IdxT>& R, const GridParams& 
     R.pend = 0u;
     R.jb = 0;
     R.pc = R.pu = R.pv = 0u;
+    R.nu_w = 0;
     R.sm = 0u;
     R.w0 = R.w1 = R.w2 = R.w3 = R.w4 = R.w5 = R.w6 = R.w7 = 0ull;
     if (miss || !(tn <= tf)) return false;
@@ -449,8 +474,8 @@ __device__ unsigned long long g_walk_hist[2 * 16];  // rays by slab steps (bucke
 
 // After a slab has been dealt with: on to the next one -- and up to the block level at the end of a block slab's eight brick
 // slabs.  Returns false when the walk leaves the grid.
-template <typename IdxT>
-__device__ __forceinline__ bool walk_advance(WalkLane<IdxT>& R)
+template <typename IdxT, bool WIDE>
+__device__ __forceinline__ bool walk_advance(WalkLane<IdxT, WIDE>& R)
 {
     const int s = R.iw > 0.0f ? 1 : -1;
     const int k = R.k;
@@ -466,22 +491,22 @@ __device__ __forceinline__ bool walk_advance(WalkLane<IdxT>& R)
 // Level 0, entering a brick: the brick's eight slab words are ONE 64-byte line (four 16-byte loads in flight together -- the
 // walk is bound by dependent memory round trips, not by issue); slabs whose word misses the rectangle the ray sweeps across the
 // whole brick slab are dropped here without any arithmetic.
-template <typename IdxT>
-__device__ __forceinline__ void walk_fetch_brick(WalkLane<IdxT>& R, const WalkHot& P VX_W_SITE_DECL)
+template <typename IdxT, bool WIDE>
+__device__ __forceinline__ void walk_fetch_brick(WalkLane<IdxT, WIDE>& R, const WalkHot& P VX_W_SITE_DECL)
 {
     VX_W_SITE(3)
-    const int nu = (int)((R.pend >> 16) & 0x7FFFu);
+    const int nu = WIDE ? R.nu_w : (int)((R.pend >> 16) & 0x7FFFu);
     const int j = R.jb + __ffs(R.pend & 0xFFFFu) - 1;
     int jv = 0, ju = j;  // j = jv * nu + ju, by subtraction (nu >= 1)
     while (ju >= nu) { ju -= nu; ++jv; }
-    const int cu = (int)(R.pc & 0xFFFFu) + ju, cv = (int)(R.pc >> 16) + jv;
+    const int cu = pk_lo<WIDE>(R.pc) + ju, cv = pk_hi<WIDE>(R.pc) + jv;
     int bx, by, bz;
     unperm(R.perm, cu, cv, R.k, bx, by, bz);
     const uint32_t bi = (uint32_t)bx + P.d1[0] * ((uint32_t)by + P.d1[1] * (uint32_t)bz);
     const ulonglong2* wp = reinterpret_cast<const ulonglong2*>(P.bricks3 + (uint64_t)R.perm * P.ori_stride + (uint64_t)bi * 8ull);
     const ulonglong2 w01 = wp[0], w23 = wp[1], w45 = wp[2], w67 = wp[3];
     const int bu = cu << 3, bv = cv << 3;
-    const int u0 = (int)(R.pu & 0xFFFFu), u1 = (int)(R.pu >> 16), v0 = (int)(R.pv & 0xFFFFu), v1 = (int)(R.pv >> 16);
+    const int u0 = pk_lo<WIDE>(R.pu), u1 = pk_hi<WIDE>(R.pu), v0 = pk_lo<WIDE>(R.pv), v1 = pk_hi<WIDE>(R.pv);
     const int a0 = (u0 > bu ? u0 : bu) - bu, a1 = (u1 < bu + 7 ? u1 : bu + 7) - bu;  // columns of the brick slab's rectangle inside this brick
     const int b0 = (v0 > bv ? v0 : bv) - bv, b1 = (v1 < bv + 7 ? v1 : bv + 7) - bv;  // rows
     const unsigned long long col = rep8((2u << a1) - (1u << a0));
@@ -494,21 +519,21 @@ __device__ __forceinline__ void walk_fetch_brick(WalkLane<IdxT>& R, const WalkHo
     if (R.iw > 0.0f) sm &= s0 <= 0 ? 0xFFu : (s0 > 7 ? 0u : (0xFFu << s0));
     else sm &= s0 >= 7 ? 0xFFu : (s0 < 0 ? 0u : (2u << s0) - 1u);
     R.sm = sm & 0xFFu;
-    R.pc = (uint32_t)cu | ((uint32_t)cv << 16);  // from here on: the brick itself (its rectangle cell is popped from R.pend below)
+    R.pc = pk_make<WIDE>(cu, cv);  // from here on: the brick itself (its rectangle cell is popped from R.pend below)
 }
 
 // Level 0, a brick is done (or a brick slab's rectangle has just been found occupied): on to the next occupied brick of the
 // rectangle; after the last one back to level 1 and on to the next slab.  Returns false when the ray is finished.
-template <typename IdxT>
-__device__ __forceinline__ bool walk_bricks(WalkLane<IdxT>& R, const WalkHot& P, bool pop, bool dead VX_W_SITE_DECL)
+template <typename IdxT, bool WIDE>
+__device__ __forceinline__ bool walk_bricks(WalkLane<IdxT, WIDE>& R, const WalkHot& P, bool pop, bool dead VX_W_SITE_DECL)
 {
     for (;;) {
         if (pop) {  // R.pc goes back to the rectangle's first brick for the decode of the next one
             const uint32_t low = R.pend & 0xFFFFu;
-            const int nu = (int)((R.pend >> 16) & 0x7FFFu);
+            const int nu = WIDE ? R.nu_w : (int)((R.pend >> 16) & 0x7FFFu);
             int jv = 0, ju = R.jb + __ffs(low) - 1;  // the finished brick was rectangle cell j = jb + ffs(low) - 1
             while (ju >= nu) { ju -= nu; ++jv; }
-            R.pc = (uint32_t)((int)(R.pc & 0xFFFFu) - ju) | ((uint32_t)((int)(R.pc >> 16) - jv) << 16);
+            R.pc = pk_make<WIDE>(pk_lo<WIDE>(R.pc) - ju, pk_hi<WIDE>(R.pc) - jv);
             R.pend = (R.pend & 0xFFFF0000u) | (low & (low - 1u));
         }
         if (!(R.pend & 0xFFFFu)) break;
@@ -528,9 +553,9 @@ __device__ __forceinline__ bool walk_bricks(WalkLane<IdxT>& R, const WalkHot& P,
 // One step of the walk = one slab: a block slab (level 2), a brick slab (level 1), or one 1-cell slab of the brick being walked
 // (level 0).  All three share the slab's [ta, tb], the termination test and the rectangle of cells; they differ in what the
 // rectangle is looked up in.  Returns false when the ray is finished.
-template <bool LDS_MIPS, typename IdxT>
-__device__ __forceinline__ bool walk_step(WalkLane<IdxT>& R, const WalkHot& P, const uint32_t* __restrict__ mips_lds, bool& xpend, uint4* __restrict__ xslot,
-                                          uint32_t& fstate VX_W_SITE_DECL)
+template <bool LDS_MIPS, typename IdxT, bool WIDE>
+__device__ __forceinline__ bool walk_step(WalkLane<IdxT, WIDE>& R, const WalkHot& P, const uint32_t* __restrict__ mips_lds, bool& xpend, uint4* __restrict__ xslot,
+                                          uint32_t* __restrict__ xslot_hi /*WIDE: the upper half of the parked brick coordinates*/, uint32_t& fstate VX_W_SITE_DECL)
 {
     VX_W_SITE(2)
     const GridParams& g = P.g;
@@ -573,7 +598,7 @@ __device__ __forceinline__ bool walk_step(WalkLane<IdxT>& R, const WalkHot& P, c
             // (selection BY VALUE: `c ? R.a : R.b` on struct members is an lvalue conditional -- clang selects the address and the lane
             // state ends up in scratch memory)
             const unsigned long long bits = sel8(sl, R.w0, R.w1, R.w2, R.w3, R.w4, R.w5, R.w6, R.w7);
-            const int bu = (int)(R.pc & 0xFFFFu) << 3, bv = (int)(R.pc >> 16) << 3;
+            const int bu = pk_lo<WIDE>(R.pc) << 3, bv = pk_hi<WIDE>(R.pc) << 3;
             int a0 = u0 - bu, a1 = u1 - bu, b0 = v0 - bv, b1 = v1 - bv;
             a0 = a0 < 0 ? 0 : a0; b0 = b0 < 0 ? 0 : b0;
             a1 = a1 > 7 ? 7 : a1; b1 = b1 > 7 ? 7 : b1;
@@ -586,7 +611,8 @@ __device__ __forceinline__ bool walk_step(WalkLane<IdxT>& R, const WalkHot& P, c
                 // The exact tests are not done here, where one lane in sixteen has candidates: the lane parks them in its LDS slot
                 // and sits out the rest of the round; all parked lanes of the wave test together at the end of the round (walk_exact).
                 // Until then the lane's best hit is stale, which only postpones the pruning that depends on it.
-                *xslot = make_uint4((uint32_t)cand, (uint32_t)(cand >> 32), (uint32_t)k, R.pc);
+                *xslot = make_uint4((uint32_t)cand, (uint32_t)(cand >> 32), (uint32_t)k, (uint32_t)R.pc);
+                if (WIDE) *xslot_hi = (uint32_t)((unsigned long long)R.pc >> 32);
                 xpend = true;
             }
         } else {
@@ -654,10 +680,11 @@ __device__ __forceinline__ bool walk_step(WalkLane<IdxT>& R, const WalkHot& P, c
                     return true;
                 }
                 // the occupied bricks of this brick slab's rectangle: walked one after the other at level 0
-                R.pend = occ | ((uint32_t)nu << 16) | (more ? 0x80000000u : 0u);
-                R.pc = (uint32_t)cu0 | ((uint32_t)cv0 << 16);
-                R.pu = (uint32_t)u0 | ((uint32_t)u1 << 16);
-                R.pv = (uint32_t)v0 | ((uint32_t)v1 << 16);
+                R.pend = occ | (WIDE ? 0u : ((uint32_t)nu << 16)) | (more ? 0x80000000u : 0u);
+                if (WIDE) R.nu_w = nu;
+                R.pc = pk_make<WIDE>(cu0, cv0);
+                R.pu = pk_make<WIDE>(u0, u1);
+                R.pv = pk_make<WIDE>(v0, v1);
                 R.lvl = 0;
                 R.sm = 0u;
                 brick_done = true;  // "no brick loaded yet": fetch the first one below
@@ -685,14 +712,14 @@ __device__ __forceinline__ bool walk_step(WalkLane<IdxT>& R, const WalkHot& P, c
 }
 
 // The exact tests of the candidates a lane parked in its LDS slot: hitAabb on every candidate cell of one 1-cell slab of a brick.
-template <typename IdxT>
-__device__ __forceinline__ void walk_exact(WalkLane<IdxT>& R, const WalkHot& P, const uint4* __restrict__ xslot VX_W_SITE_DECL)
+template <typename IdxT, bool WIDE>
+__device__ __forceinline__ void walk_exact(WalkLane<IdxT, WIDE>& R, const WalkHot& P, const uint4* __restrict__ xslot, const uint32_t* __restrict__ xslot_hi VX_W_SITE_DECL)
 {
     const GridParams& g = P.g;
     const uint4 xs = *xslot;
     unsigned long long cand = (unsigned long long)xs.x | ((unsigned long long)xs.y << 32);
     const int k = (int)xs.z;
-    const int bu = (int)(xs.w & 0xFFFFu) << 3, bv = (int)(xs.w >> 16) << 3;
+    const int bu = (WIDE ? (int)xs.w : (int)(xs.w & 0xFFFFu)) << 3, bv = (WIDE ? (int)*xslot_hi : (int)(xs.w >> 16)) << 3;
     // the slab's own box planes along w (voxelgridBool.cpp:37-41: c -/+ half with c = org + (i + 0.5) * vs) and their hitAabb terms
     const float cw = R.orgw + (((float)k + 0.5f) * g.vs);
     const float bw = R.iw * ((cw - g.half) - R.ow), tw = R.iw * ((cw + g.half) - R.ow);
@@ -739,7 +766,7 @@ __device__ __forceinline__ float shfl_fw(float v, int src) { return __shfl(v, sr
 // Persistent waves with dynamic work fetch.  Exit condition every wave reaches: the work counter passes the ray count (no
 // refill possible) and every lane's ray has finished; a ray finishes in a bounded number of slabs (its index along the major
 // axis is monotone at both levels).
-template <bool LDS_MIPS, typename IdxT>
+template <bool LDS_MIPS, typename IdxT, bool WIDE = false>
 __global__ __launch_bounds__(VX_W_BLOCK, VX_W_MINWAVES) void k_walk(const WalkParams PP)
 {
     const WalkHot& P = PP.hot;
@@ -766,11 +793,12 @@ __global__ __launch_bounds__(VX_W_BLOCK, VX_W_MINWAVES) void k_walk(const WalkPa
     __shared__ unsigned long long don_key[VX_W_BLOCK];
     __shared__ unsigned don_cnt[VX_W_BLOCK];
     __shared__ uint4 xslots[VX_W_BLOCK];  // per lane: the candidate cells parked for the round's exact-test phase
+    __shared__ uint32_t xslots_hi[WIDE ? VX_W_BLOCK : 1];
     bool xpend = false;
     uint32_t fstate = 0u;  // bit 0: the lane waits for the round's brick phase; bits 1, 2: walk_bricks' pop and dead
     const int lane = threadIdx.x & 63;
     int slot = -1;             // >= 0: this lane walks a PIECE of a split ray; its result goes through don_key[slot]
-    WalkLane<IdxT> R;
+    WalkLane<IdxT, WIDE> R;
     R.pend = 0u;
 #ifdef VX_W_DEBUG
     unsigned dbg_w[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dbg_l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -934,12 +962,12 @@ __global__ __launch_bounds__(VX_W_BLOCK, VX_W_MINWAVES) void k_walk(const WalkPa
 #ifdef VX_W_DEBUG
             if (go) ++dbg_steps;
 #endif
-            if (go && !walk_step<LDS_MIPS>(R, P, mips_lds, xpend, &xslots[threadIdx.x], fstate VX_W_SITE_ARGS)) finished = true;
+            if (go && !walk_step<LDS_MIPS>(R, P, mips_lds, xpend, &xslots[threadIdx.x], &xslots_hi[WIDE ? threadIdx.x : 0], fstate VX_W_SITE_ARGS)) finished = true;
         }
         // ---- exact tests of the candidates the steps parked
         if (__ballot(xpend)) {
             if (xpend) {
-                walk_exact(R, P, &xslots[threadIdx.x] VX_W_SITE_ARGS);
+                walk_exact(R, P, &xslots[threadIdx.x], &xslots_hi[WIDE ? threadIdx.x : 0] VX_W_SITE_ARGS);
                 xpend = false;
                 if (P.any_hit && R.best_idx != (IdxT)~(IdxT)0) finished = true;  // shadow query (gl_RayFlagsTerminateOnFirstHitEXT, raytrace2.rchit:108)
             }
@@ -1046,7 +1074,8 @@ void launch_walk(const GridParams& g, const TraceMips& mips, const TraceIO& io, 
     const uint32_t m1_words = (uint32_t)((n1 + 31) / 32), m2_words = (uint32_t)((n2 + 31) / 32);
     // VOXHIP_TRACE_LDS=0 forces the global-memory mips (the path every grid above ~550^3 takes) -- used by the parity tests
     const char* env_lds = getenv("VOXHIP_TRACE_LDS");
-    const bool lds = (size_t)(m1_words + m2_words) * 4 <= 32768 + 1024 && !(env_lds && atoi(env_lds) == 0);
+    const bool wide = g.dim[0] > 65535u || g.dim[1] > 65535u || g.dim[2] > 65535u;  // cell coordinates beyond 16 bits: the WIDE variants (global-memory mips only)
+    const bool lds = !wide && (size_t)(m1_words + m2_words) * 4 <= 32768 + 1024 && !(env_lds && atoi(env_lds) == 0);
     const int env_blocks = getenv("VOXHIP_TRACE_BLOCKS") ? atoi(getenv("VOXHIP_TRACE_BLOCKS")) : 0;
     WalkParams P;
     std::memset(&P, 0, sizeof(P));
@@ -1091,6 +1120,8 @@ void launch_walk(const GridParams& g, const TraceMips& mips, const TraceIO& io, 
         const dim3 grid((unsigned)nblk), block(VX_W_BLOCK);
         if (lds) {
             if (idx32) VX_KL((k_walk<true, uint32_t>), grid, block, shmem, s, P); else VX_KL((k_walk<true, unsigned long long>), grid, block, shmem, s, P);
+        } else if (wide) {
+            if (idx32) VX_KL((k_walk<false, uint32_t, true>), grid, block, shmem, s, P); else VX_KL((k_walk<false, unsigned long long, true>), grid, block, shmem, s, P);
         } else {
             if (idx32) VX_KL((k_walk<false, uint32_t>), grid, block, shmem, s, P); else VX_KL((k_walk<false, unsigned long long>), grid, block, shmem, s, P);
         }

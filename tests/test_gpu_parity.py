@@ -166,10 +166,22 @@ def test_axis_above_65535_cells(gpu):
     gm = gpu.Grid.voxelize(mesh, vs, gpu.GRID_BOOL, materials=True)
     oids, order = oracle.material_ids(v, t, vs, tv, nvalues)
     assert np.array_equal(gm.bitmask(), ow) and np.array_equal(gm.materials()[1], oids)
-    # rays on such a grid are refused, not wrong
-    with pytest.raises(gpu.VxError) as ei:
-        gm.trace(vx_scenes.random_rays(16, gi["bmin"], gi["bmax"], seed=1))
-    assert ei.value.status == 9   # VX_ERR_UNSUPPORTED
+    # rays on the wide grid (the ray kernel's 32-bit-coordinate variants): bit-equal to the brute force over all boxes
+    oa = oracle.bool_aabbs(ow, gi, vs)
+    rng = np.random.default_rng(17)
+    n = 6000
+    o = np.stack([rng.uniform(-2000.0, 102000.0, n), rng.uniform(-30.0, 40.0, n), rng.uniform(-30.0, 40.0, n)], 1)
+    tgt = np.stack([rng.uniform(0.0, 100000.0, n), rng.uniform(0.0, 8.0, n), rng.uniform(0.0, 8.0, n)], 1)
+    tgt[: n // 3, 0] = o[: n // 3, 0] + rng.uniform(-300.0, 300.0, n // 3)       # steep rays across the thin axes
+    tgt[n // 3: n // 2, 0] = rng.uniform(65400.0, 65700.0, n // 2 - n // 3)      # around cell 65536
+    rays = np.concatenate([o, tgt - o], 1).astype(np.float32)
+    rays = np.concatenate([rays, np.array([[-5.0, 4.1, 3.9, 1.0, 0.0, 0.0], [100005.0, 2.2, 6.1, -1.0, 0.0, 0.0], [70000.5, -3.0, 4.5, 0.0, 1.0, 0.0]], np.float32)])
+    for grid_ in (g, gm):
+        tt, pp, _ = grid_.trace(rays, tmax=1.0e6)
+        ot, op = oracle.trace_brute(oa, rays, tmax=1.0e6)
+        assert np.array_equal(tt, ot) and np.array_equal(pp, op) and (ot > 0).mean() > 0.3
+        wt, wp = oracle.trace_walk(ow, gi, vs, rays, tmax=1.0e6)
+        assert np.array_equal(wt, ot) and np.array_equal(wp, op)
     # the reference's own limit: more than 2^21 cells on an axis
     with pytest.raises(gpu.VxError) as ei:
         gpu.Octree(mesh, np.float32(100_000 / (2 ** 21 + 5000.0)))
@@ -882,6 +894,40 @@ def test_vec_list_bound_to_caller_buffer(gpu):
     g.bind_aabbs_device(None, 0)
     g.revoxelize(mesh, np.float32(0.031))
     assert g.aabbs().tobytes() == oracle.build_vec(v, t, np.float32(0.031)).tobytes()
+
+
+def test_rebuild_after_external_write_of_the_mask(gpu):
+    """The multi-rank exchange writes the grid's bitmask from outside the library (vx_grid_bitmask_device_mut: RCCL all-gather, peer
+    copies).  A rebuild in the same handle must not see any of it: the mask is cleared by the build itself (k_tri_setup's threads
+    or a memset) before k_voxelize's plain loads decide which atomicOr requests to skip -- an external all-ones mask would
+    otherwise make every request look redundant."""
+    import torch
+    v, t = vx_scenes.scene("blob70k")
+    vs = np.float32(2.0 / 128)
+    mesh = gpu.Mesh.from_arrays(v, t)
+    ow, calls, gi = oracle.build_bool(v, t, vs)
+    for kind in (gpu.GRID_BOOL, gpu.GRID_VEC):
+        g = gpu.Grid.voxelize(mesh, vs, kind)
+        nwords = g.describe()["num_words"]
+
+        class View:
+            __cuda_array_interface__ = {"shape": (nwords,), "typestr": "<i4", "data": (g.bitmask_device_ptr(mutable=True), False), "version": 3, "strides": None}
+        for fill in (-1, 0x55555555, 0):
+            torch.as_tensor(View(), device="cuda").fill_(fill)      # the "exchange": every word overwritten from outside
+            torch.cuda.synchronize()
+            g.revoxelize(mesh, vs)
+            assert np.array_equal(g.bitmask(), ow), "fill %x, kind %d" % (fill & 0xFFFFFFFF, kind)
+            for sh in ((0, 2), (1, 2)):   # and word shards of it, as a rank of a multi-GPU build rebuilds them
+                torch.as_tensor(View(), device="cuda").fill_(fill)
+                torch.cuda.synchronize()
+                if kind == gpu.GRID_BOOL:
+                    g.revoxelize(mesh, vs, shard=sh)
+                    wb, we, _ = gpu.shard_words(nwords, sh[0], sh[1])
+                    exp = np.zeros_like(ow)
+                    exp[wb:we] = ow[wb:we]
+                    assert np.array_equal(g.bitmask(), exp)
+        g.revoxelize(mesh, vs)
+        assert np.array_equal(g.bitmask(), ow) and g.describe()["set_calls"] == calls
 
 
 def test_rebuilds_alternating_meshes_same_grid(gpu):
