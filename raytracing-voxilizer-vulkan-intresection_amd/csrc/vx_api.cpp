@@ -134,6 +134,7 @@ struct DevBuf {
     int dev = 0;
     hipStream_t stream = nullptr;  // the stream the owner queues this buffer's work on (set by the owning handle)
     bool fresh = false;  // set when ensure() handed out a new block (contents undefined); the owner clears it
+    uint32_t scan_gen = 0;  // scan scratch only: the number of the last scan that used this block (generation mode of the single-pass scan)
     hipError_t ensure(size_t bytes)
     {
         if (bytes <= cap && p) return hipSuccess;
@@ -229,8 +230,20 @@ hipError_t ensure_scan_tmp(DevBuf& tmp, size_t bytes, hipStream_t s)
     hipError_t e = tmp.ensure(bytes);
     if (e != hipSuccess || !tmp.fresh) return e;
     e = hipMemsetAsync(tmp.p, 0, tmp.cap, s);
-    if (e == hipSuccess) tmp.fresh = false;
+    if (e == hipSuccess) { tmp.fresh = false; tmp.scan_gen = 0; }
     return e;
+}
+
+// the number of the next scan on this scratch block (generation mode: state words of older scans read as "not there yet")
+uint32_t next_scan_gen(DevBuf& tmp, hipStream_t s)
+{
+    static const bool off = getenv("VOXHIP_SCAN_GEN") && atoi(getenv("VOXHIP_SCAN_GEN")) == 0;  // 0: tickets + self-cleaning state (A/B, tests)
+    if (off) return 0u;
+    if (++tmp.scan_gen >= (1u << 22)) {
+        (void)hipMemsetAsync(tmp.p, 0, tmp.cap, s);
+        tmp.scan_gen = 1u;
+    }
+    return tmp.scan_gen;
 }
 
 }  // namespace
@@ -474,7 +487,8 @@ vx_status setup_launch(const vx_mesh* m, const vx::GridParams& g, int sat, uint6
     VX_HIP(ensure_scan_tmp(scantmp, vx::scan_tmp_bytes(ntri), s));
     vx::launch_tri_setup(m->dv, m->di, tb, ntri, g, sat, zlo, zhi, recs.as<vx::TriRec>(), units.as<uint32_t>(), s, dgrid, clear, clear_bytes, shard_wb, shard_we,
                          ext.as<uint32_t>(), shard_rank, shard_world);
-    const bool tg = vx::launch_scan_u32(units.as<uint32_t>(), ubase.as<uint32_t>(), ntri, false, scantmp.p, &mail->units, s, true, mail_tag);
+    const bool tg = vx::launch_scan_u32(units.as<uint32_t>(), ubase.as<uint32_t>(), ntri, false, scantmp.p, &mail->units, s, true, mail_tag, nullptr,
+                                        next_scan_gen(scantmp, s));
     if (tagged) *tagged = tg && mail_tag != 0;
     return VX_OK;
 }
@@ -509,7 +523,7 @@ vx_status prefix_launch(vx_grid* g, bool* pending, unsigned long long tag = 0, b
     VX_HIP(g->wsel.ensure((size_t)(g->g.nwords / 32 + 4) * 4));  // at most 32 nwords / 1024 chunks of 1024 records
     VX_HIP(ensure_scan_tmp(g->scantmp, vx::scan_tmp_bytes(g->g.nwords), g->stream));
     const bool tg = vx::launch_scan_u32(g->words.as<uint32_t>(), g->wprefix.as<uint32_t>(), g->g.nwords, true, g->scantmp.p, &g->mail->occupied, g->stream, true, tag,
-                                        g->wsel.as<uint32_t>());
+                                        g->wsel.as<uint32_t>(), next_scan_gen(g->scantmp, g->stream));
     g->sel_valid = tg;  // (the three-pass scan does not write it)
     if (tagged) *tagged = tg;
     g->occ_tag = tg ? tag : 0;  // what the host may poll the mailbox for instead of draining the stream (prefix_finish)
@@ -928,7 +942,7 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
         // VoxelGridVec::setVoxel appends one Aabb per call (voxelgridVecEncoding.cpp:19-39): ordered emission
         VX_HIP(g->hbase.ensure((size_t)(U + 2) * 4));
         VX_HIP(ensure_scan_tmp(g->scantmp, vx::scan_tmp_bytes(U), s));
-        hits_tagged = vx::launch_scan_u32(umask, g->hbase.as<uint32_t>(), U, true, g->scantmp.p, &g->mail->hits, s, true, mtag);
+        hits_tagged = vx::launch_scan_u32(umask, g->hbase.as<uint32_t>(), U, true, g->scantmp.p, &g->mail->hits, s, true, mtag, nullptr, next_scan_gen(g->scantmp, s));
     }
     // A complete (unsharded) bitmask: queue what every consumer of the grid needs next -- the traversal structure (bricks,
     // bounds, mips = the reference's acceleration-structure build, hello_vulkan.cpp:700-703) and the word prefix (getAabbs /
@@ -1747,7 +1761,7 @@ vx_status vx_octree_build(const vx_mesh* mesh_c, float vs, uint64_t max_items, v
         OCT_HIP(hbase.ensure((size_t)(U + 2) * 4));
         OCT_HIP(ensure_scan_tmp(scantmp, vx::scan_tmp_bytes(U), s));
         vx::launch_voxelize(recs.as<vx::TriRec>(), ubase.as<uint32_t>(), btri.as<uint32_t>(), ntri, g, 0, nullptr, 0, 0, umask.as<uint32_t>(), ds->set_calls, s, xw);
-        vx::launch_scan_u32(umask.as<uint32_t>(), hbase.as<uint32_t>(), U, true, scantmp.p, &mail->hits, s, true);
+        vx::launch_scan_u32(umask.as<uint32_t>(), hbase.as<uint32_t>(), U, true, scantmp.p, &mail->hits, s, true, 0, nullptr, next_scan_gen(scantmp, s));
         OCT_HIP(hipStreamSynchronize(s));
         hits = mail->hits & kMailValue;
         if (hits >= 0xFFFFFFFFull) return bail(fail(VX_ERR_CAPACITY, "more than 2^32 octree items"));
@@ -1760,7 +1774,9 @@ vx_status vx_octree_build(const vx_mesh* mesh_c, float vs, uint64_t max_items, v
                               nullptr, unsorted.as<uint64_t>(), s, ~0ull, xw);
         const size_t tb = vx::sort_tmp_bytes(hits);
         OCT_HIP(sorttmp.ensure(tb));
-        vx::launch_sort_u64(unsorted.as<uint64_t>(), o->items.as<uint64_t>(), hits, o->bits ? (int)(3 * o->bits) : 1, sorttmp.p, tb, s);  // octTree.hpp:363
+        // octTree.hpp:363; the sort ping-pongs between the two buffers: whichever holds the result becomes the octree's item list
+        if (vx::launch_sort_u64(unsorted.as<uint64_t>(), o->items.as<uint64_t>(), hits, o->bits ? (int)(3 * o->bits) : 1, sorttmp.p, tb, s) == 0)
+            std::swap(unsorted, o->items);
     }
     // node array (octTree.hpp:319-358, :371)
     if (hits && max_items <= vx::kOctDirectMaxItems) {
@@ -1770,7 +1786,7 @@ vx_status vx_octree_build(const vx_mesh* mesh_c, float vs, uint64_t max_items, v
         OCT_HIP(nbase.ensure(((size_t)ni + 2) * 4));
         OCT_HIP(ensure_scan_tmp(scantmp, vx::scan_tmp_bytes(ni), s));
         vx::launch_oct_depths(o->items.as<uint64_t>(), ni, o->bits, (uint32_t)max_items, ncount.as<uint8_t>(), s);
-        vx::launch_scan_u8(ncount.as<uint8_t>(), nbase.as<uint32_t>(), ni, scantmp.p, &mail->occupied, s);
+        vx::launch_scan_u8(ncount.as<uint8_t>(), nbase.as<uint32_t>(), ni, scantmp.p, &mail->occupied, s, 0, next_scan_gen(scantmp, s));
         OCT_HIP(hipStreamSynchronize(s));
         const unsigned long long nn = mail->occupied & kMailValue;
         if (nn == 0 || nn >= 0xFFFFFFFFull) return bail(fail(VX_ERR_CAPACITY, "more than 2^32 octree nodes"));

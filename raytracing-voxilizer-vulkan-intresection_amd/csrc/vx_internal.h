@@ -73,10 +73,11 @@ size_t scan_tmp_bytes(uint64_t n);
 // this scan's total from an older one; returns whether the tag was applied (false: the three-pass path, *total64 is the bare total).
 bool launch_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, bool popcount_input, void* tmp,
                      unsigned long long* total64, hipStream_t s, bool tmp_is_zero = false, unsigned long long total_tag = 0,
-                     uint32_t* sel1024 = nullptr /*optional (single-pass kernel only, values <= 1024): sel1024[c] = the element whose range holds c * 1024*/);
+                     uint32_t* sel1024 = nullptr /*optional (single-pass kernel only, values <= 1024): sel1024[c] = the element whose range holds c * 1024*/,
+                     uint32_t gen = 0 /*generation mode (vx_kernels.hip): the number of this scan on `tmp`, 1, 2, 3 ... < 2^22; 0 = tickets + self-cleaning state*/);
 
 void launch_scan_u8(const uint8_t* in, uint32_t* out, uint64_t n, void* tmp /*scan_tmp_bytes(n), all zero*/, unsigned long long* total64, hipStream_t s,
-                    unsigned long long total_tag = 0);
+                    unsigned long long total_tag = 0, uint32_t gen = 0);
 
 // K2: triangle/voxel overlap over all work units; ORs hits into `words` (only words in [wb,we)), optionally
 // stores each unit's 32-bit hit mask (unit_mask) for the ordered emitters; adds the hit count to *set_calls.
@@ -148,9 +149,10 @@ void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* wo
 // single-voxel helpers
 void launch_set_bit(uint32_t* words, uint64_t idx, hipStream_t s);
 
-// device radix sort of uint64 keys (octree items); tmp sized by sort_tmp_bytes
+// device radix sort of uint64 keys (octree items; vx_sort.hip); tmp sized by sort_tmp_bytes.  The two key buffers ping-pong:
+// returns 0 when the sorted keys end up in keys_a, 1 for keys_b (the other buffer is scratch afterwards).
 size_t sort_tmp_bytes(uint64_t n);
-void launch_sort_u64(uint64_t* keys_in, uint64_t* keys_out, uint64_t n, int bits, void* tmp, size_t tmp_bytes, hipStream_t s);
+int launch_sort_u64(uint64_t* keys_a /*in*/, uint64_t* keys_b, uint64_t n, int bits, void* tmp, size_t tmp_bytes, hipStream_t s);
 
 // Octree node array, direct form (max_items <= kOctDirectMaxItems): per item position the number of nodes that START there
 // (launch_oct_depths, bytes), an exclusive scan of those = the pre-order index of the first of them, then start / count / child links

@@ -285,6 +285,15 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_apply(const uint32_t* __res
 // Flag and value travel in the same word, so relaxed agent-scope atomics are enough (acquire/release would add a cache
 // invalidate / write-back to every poll: measured 190 us per scan instead of 40).
 constexpr unsigned long long kScanFlagA = 1ull << 62, kScanFlagP = 2ull << 62, kScanValMask = (1ull << 62) - 1ull;
+// GENERATION MODE (gen != 0; scans of at most kScanGenTiles tiles, i.e. every workgroup of the launch is resident at once):
+//   * tiles are taken in blockIdx order instead of by ticket -- a workgroup never waits for one that is not running yet, and the
+//     returning atomic in front of everything else (~2 us) is gone;
+//   * a state word carries the scan's generation number in bits 40..61 (value in bits 0..39): a word of an older scan on the same
+//     buffer reads as "not there yet", so nothing has to be cleaned up -- the finished-tiles counter, its returning atomic and the
+//     zeroing loop are gone as well.  The caller numbers the scans of a buffer 1, 2, 3, ... (and clears the buffer when the number
+//     wraps at 2^22); a buffer fresh from the allocator is cleared once.
+constexpr uint32_t kScanGenTiles = 512;
+constexpr unsigned long long kScanGenValMask = (1ull << 40) - 1ull;
 
 // Large tiles (1024 threads x 16 elements): a 4M-element scan is 256 tiles, so the look-back chain is a handful of hops
 // (with 2048-element tiles the chain of 2048 hops at cross-XCD atomic latency cost as much as the three-pass scan).
@@ -301,14 +310,21 @@ template <int MODE>
 __global__ __launch_bounds__(kOneBlock) void k_scan_onepass(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t n,
                                                            unsigned long long* status /*[0]: ticket, [1]: finished tiles, [2 + tile]: state*/, uint32_t ntiles,
                                                            unsigned long long* total, unsigned long long total_tag /*OR-ed into *total: bits 48..63*/,
-                                                           uint32_t* __restrict__ sel /*optional: sel[c] = index of the element whose range [pre, pre + v) holds c * 1024*/)
+                                                           uint32_t* __restrict__ sel /*optional: sel[c] = index of the element whose range [pre, pre + v) holds c * 1024*/,
+                                                           uint32_t gen /*0: tickets + self-cleaning state; else generation mode*/)
 {
     __shared__ unsigned wsum[kOneBlock / 64];
     __shared__ unsigned tile_s;
     __shared__ unsigned long long prefix_s;
-    if (threadIdx.x == 0) tile_s = (unsigned)atomicAdd(status, 1ull);
-    __syncthreads();
-    const unsigned tile = tile_s;
+    unsigned tile = blockIdx.x;
+    if (!gen) {
+        if (threadIdx.x == 0) tile_s = (unsigned)atomicAdd(status, 1ull);
+        __syncthreads();
+        tile = tile_s;
+    }
+    const unsigned long long gtag = (unsigned long long)gen << 40;                       // this scan's words: flag | gtag | value
+    const unsigned long long vmask = gen ? kScanGenValMask : kScanValMask;
+    const unsigned long long fmask = gen ? (3ull << 62) | (((1ull << 22) - 1ull) << 40) : (3ull << 62);  // what must match for a word to count
     unsigned long long* st = status + 2;
     const uint64_t base = (uint64_t)tile * kOneTile + (uint64_t)threadIdx.x * kOneItems;
     unsigned v[kOneItems];
@@ -364,23 +380,29 @@ __global__ __launch_bounds__(kOneBlock) void k_scan_onepass(const uint32_t* __re
     if (threadIdx.x < 64) {
         unsigned long long excl = 0;
         if (tile == 0) {
-            if (lane == 0) __hip_atomic_store(&st[0], kScanFlagP | (unsigned long long)btot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(&st[0], kScanFlagP | gtag | (unsigned long long)btot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            if (lane == 0) __hip_atomic_store(&st[tile], kScanFlagA | (unsigned long long)btot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(&st[tile], kScanFlagA | gtag | (unsigned long long)btot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             long long look = (long long)tile - 1;
             for (;;) {
                 const long long idx = look - lane;
                 unsigned long long w;
-                do {  // every predecessor in the window has at least started (ticket order): wait for its first word
-                    w = idx >= 0 ? __hip_atomic_load(&st[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kScanFlagP;
-                } while (__ballot((w >> 62) == 0ull));
+                bool there;
+                do {  // every predecessor in the window has at least started (ticket order / all resident): wait for its first word
+                    w = idx >= 0 ? __hip_atomic_load(&st[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (kScanFlagP | gtag);
+                    // (a word of this scan: flag A or P and, in generation mode, this scan's number)
+                    there = ((w & fmask) == (kScanFlagA | gtag)) || ((w & fmask) == (kScanFlagP | gtag));
+                } while (__ballot(!there));
                 const unsigned long long pm = __ballot((w >> 62) == 2ull);
                 const int first_p = pm ? __ffsll((long long)pm) - 1 : 64;
-                excl += wave_sum_u64(lane <= first_p ? (w & kScanValMask) : 0ull);
+                excl += wave_sum_u64(lane <= first_p ? (w & vmask) : 0ull);
                 if (pm) break;
                 look -= 64;
             }
-            if (lane == 0) __hip_atomic_store(&st[tile], kScanFlagP | (excl + (unsigned long long)btot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (generation mode keeps 40 value bits: sums saturate there instead of running into the generation number -- a total that
+            // large is far beyond what the 32-bit outputs can address and is reported as a capacity error by every caller)
+            if (excl + (unsigned long long)btot > vmask) excl = vmask - (unsigned long long)btot;
+            if (lane == 0) __hip_atomic_store(&st[tile], kScanFlagP | gtag | (excl + (unsigned long long)btot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (lane == 0) {
             prefix_s = excl;
@@ -418,7 +440,7 @@ __global__ __launch_bounds__(kOneBlock) void k_scan_onepass(const uint32_t* __re
     // self-cleaning: the tile that finishes its look-back last (nobody reads a state word any more) zeroes the ticket, the
     // counter and every state word, so the next scan on this buffer needs no memset.  Last thing the workgroup does: the
     // counter's old value takes microseconds to come back and nothing else has to wait for it.
-    if (threadIdx.x < 64) {
+    if (!gen && threadIdx.x < 64) {
         unsigned long long fin = 0;
         if (lane == 0) fin = atomicAdd(&status[1], 1ull);
         fin = shfl_u64_k(fin, 0);
@@ -431,7 +453,7 @@ __global__ __launch_bounds__(kOneBlock) void k_scan_onepass(const uint32_t* __re
 size_t scan_tmp_bytes(uint64_t n) { return (size_t)(((n + 1) + kScanTile - 1) / kScanTile + 4) * sizeof(unsigned long long); }
 
 bool launch_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, bool popcount_input, void* tmp, unsigned long long* total64,
-                     hipStream_t s, bool tmp_is_zero, unsigned long long total_tag, uint32_t* sel1024)
+                     hipStream_t s, bool tmp_is_zero, unsigned long long total_tag, uint32_t* sel1024, uint32_t gen)
 {
     const uint32_t nblocks = (uint32_t)(((n + 1) + kScanTile - 1) / kScanTile);
     unsigned long long* status = (unsigned long long*)tmp;
@@ -439,9 +461,12 @@ bool launch_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, bool popcoun
     const bool aligned = ((((uintptr_t)in) | ((uintptr_t)out)) & 15u) == 0;  // the single-pass kernel moves 16-byte vectors
     if (!three_pass && aligned) {
         const uint32_t ntiles = (uint32_t)(((n + 1) + kOneTile - 1) / kOneTile);
-        if (!tmp_is_zero) (void)hipMemsetAsync(status, 0, (size_t)(ntiles + 2) * sizeof(unsigned long long), s);
-        if (popcount_input) VX_KL(k_scan_onepass<1>, dim3(ntiles), dim3(kOneBlock), 0, s, in, out, n, status, ntiles, total64, total_tag, sel1024);
-        else VX_KL(k_scan_onepass<0>, dim3(ntiles), dim3(kOneBlock), 0, s, in, out, n, status, ntiles, total64, total_tag, sel1024);
+        // generation mode: small scans only (every tile resident).  A larger scan on a generation-managed buffer clears its state words
+        // first (they hold older scans' words) and runs with tickets, which leaves them zero again.
+        const uint32_t g = (gen && ntiles <= kScanGenTiles) ? gen : 0u;
+        if (!g && (!tmp_is_zero || gen)) (void)hipMemsetAsync(status, 0, (size_t)(ntiles + 2) * sizeof(unsigned long long), s);
+        if (popcount_input) VX_KL(k_scan_onepass<1>, dim3(ntiles), dim3(kOneBlock), 0, s, in, out, n, status, ntiles, total64, total_tag, sel1024, g);
+        else VX_KL(k_scan_onepass<0>, dim3(ntiles), dim3(kOneBlock), 0, s, in, out, n, status, ntiles, total64, total_tag, sel1024, g);
         return true;
     }
     unsigned long long* sums = status;
@@ -454,16 +479,18 @@ bool launch_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, bool popcoun
         VX_KL(k_scan_spine, dim3(1), dim3(1024), 0, s, sums, nblocks, total64);
         VX_KL(k_scan_apply<false>, dim3(nblocks), dim3(kScanBlock), 0, s, in, out, n, sums);
     }
-    if (tmp_is_zero) (void)hipMemsetAsync(status, 0, scan_tmp_bytes(n), s);  // keep the caller's "zero between scans" contract
+    if (tmp_is_zero || gen) (void)hipMemsetAsync(status, 0, scan_tmp_bytes(n), s);  // keep the caller's "zero between scans" contract (no stale words either)
     return false;  // (*total64 carries no tag)
 }
 
 // exclusive scan of n BYTES into out[0..n] (uint32); single-pass kernel only (in and out 16-byte aligned, tmp all zero before and after)
-void launch_scan_u8(const uint8_t* in, uint32_t* out, uint64_t n, void* tmp, unsigned long long* total64, hipStream_t s, unsigned long long total_tag)
+void launch_scan_u8(const uint8_t* in, uint32_t* out, uint64_t n, void* tmp, unsigned long long* total64, hipStream_t s, unsigned long long total_tag, uint32_t gen)
 {
     const uint32_t ntiles = (uint32_t)(((n + 1) + kOneTile - 1) / kOneTile);
+    const uint32_t g = (gen && ntiles <= kScanGenTiles) ? gen : 0u;
+    if (!g && gen) (void)hipMemsetAsync(tmp, 0, (size_t)(ntiles + 2) * sizeof(unsigned long long), s);
     VX_KL(k_scan_onepass<2>, dim3(ntiles), dim3(kOneBlock), 0, s, reinterpret_cast<const uint32_t*>(in), out, n, (unsigned long long*)tmp, ntiles, total64, total_tag,
-          (uint32_t*)nullptr);
+          (uint32_t*)nullptr, g);
 }
 
 // ------------------------------------------------------------------------------------------------------------

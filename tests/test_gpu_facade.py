@@ -127,11 +127,13 @@ def test_cli_render_matches_oracle_shade(gpu, tmp_path):
     vs = np.float32(0.05)
     ow, _, gi = oracle.build_bool(v, t, vs)
     oa = oracle.bool_aabbs(ow, gi, vs)
-    for with_mat in (False, True):
+    for with_mat in (False, True, "sharded"):
         ppm, cam, md = tmp_path / "o.ppm", tmp_path / "cam.bin", tmp_path / "mat.bin"
         cmd = [os.path.join(PKG, "voxilizer"), str(obj), "0.05", "--render", str(ppm), "--size", "%dx%d" % (W, H), "--camera-dump", str(cam)]
         if with_mat:
             cmd += ["--materials", "--dump-materials", str(md)]
+        if with_mat == "sharded":   # VoxelBuilder::withMaterials() + withDevices(): the same ids from three word shards (logical ranks)
+            cmd += ["--gpus", "3", "--logical"]
         r = run(cmd)
         assert r.returncode == 0, r.stdout
         raw = open(ppm, "rb").read()
