@@ -12,7 +12,8 @@
 //   k_sort_scatter  re-reads the tile (wave w owns 1024 consecutive keys, 64 per round: 512-byte loads), ranks every key among the
 //                   equal digits before it -- per wave and round by a ballot per digit bit (the lanes that share my digit), carried
 //                   across rounds in the wave's own LDS counters (no atomics: one wave, one counter row), across waves by a prefix
-//                   over the four rows -- and stores it at (start of my tile's digit) + (earlier waves' count) + (my rank).
+//                   over the four rows -- orders the tile by digit in LDS and stores it from there: a run of equal digits leaves as
+//                   one contiguous piece at (start of my tile's digit in the output).
 // Memory order inside a tile is (wave, round, lane) and every rank is taken in that order, so each pass is stable.
 // Traffic per pass: keys read twice and written once (24 B per key) + the counters; what bounds it is HBM.
 #include "vx_internal.h"
@@ -44,10 +45,21 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_hist(const uint64_t* __re
     __syncthreads();
     const uint64_t t0 = (uint64_t)blockIdx.x * kSortTile;
     const uint32_t mask = nd - 1u;
-#pragma unroll 4
-    for (uint32_t k = 0; k < kSortRounds; ++k) {
-        const uint64_t i = t0 + (uint64_t)k * kSortThreads + threadIdx.x;  // (the histogram does not care about the order inside the tile)
-        if (i < n) atomicAdd(&cnt[(uint32_t)(keys[i] >> shift) & mask], 1u);
+    // (the histogram does not care about the order inside the tile: two keys per 16-byte load, all eight loads of a thread in flight)
+    if (t0 + kSortTile <= n) {
+        ulonglong2 v[kSortRounds / 2];
+#pragma unroll
+        for (uint32_t k = 0; k < kSortRounds / 2; ++k) v[k] = reinterpret_cast<const ulonglong2*>(keys + t0)[k * kSortThreads + threadIdx.x];
+#pragma unroll
+        for (uint32_t k = 0; k < kSortRounds / 2; ++k) {
+            atomicAdd(&cnt[(uint32_t)(v[k].x >> shift) & mask], 1u);
+            atomicAdd(&cnt[(uint32_t)(v[k].y >> shift) & mask], 1u);
+        }
+    } else {
+        for (uint32_t k = 0; k < kSortRounds; ++k) {
+            const uint64_t i = t0 + (uint64_t)k * kSortThreads + threadIdx.x;
+            if (i < n) atomicAdd(&cnt[(uint32_t)(keys[i] >> shift) & mask], 1u);
+        }
     }
     __syncthreads();
     for (uint32_t d = threadIdx.x; d < nd; d += kSortThreads) H[(uint64_t)d * ntiles + blockIdx.x] = cnt[d];
@@ -73,11 +85,16 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t* _
     constexpr uint32_t nd = 1u << NBITS;
     __shared__ uint32_t wcnt[kSortWaves][nd];   // per wave: keys of the digit seen so far; afterwards: the earlier waves' total of the digit
     __shared__ uint32_t dbase[nd];              // where this tile's keys of the digit start in the output
+    __shared__ uint32_t dstart[nd + 1];         // where they start inside the tile once it is ordered by digit
+    __shared__ uint64_t skey[kSortTile];        // the tile ordered by digit: runs of equal digits leave as contiguous stores
+    __shared__ uint32_t wtot[kSortWaves];
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     for (uint32_t i = threadIdx.x; i < kSortWaves * nd; i += kSortThreads) (&wcnt[0][0])[i] = 0u;
     for (uint32_t d = threadIdx.x; d < nd; d += kSortThreads) dbase[d] = Hs[(uint64_t)d * ntiles + blockIdx.x];
     __syncthreads();
-    const uint64_t w0 = (uint64_t)blockIdx.x * kSortTile + (uint64_t)wv * (64u * kSortRounds);
+    const uint64_t t0 = (uint64_t)blockIdx.x * kSortTile;
+    const uint64_t w0 = t0 + (uint64_t)wv * (64u * kSortRounds);
+    const uint32_t nvalid = n - t0 < kSortTile ? (uint32_t)(n - t0) : kSortTile;  // keys of this tile (the last one may be short)
     const unsigned long long lt = (1ull << lane) - 1ull;
     uint64_t key[kSortRounds];
     uint32_t rnk[kSortRounds];   // rank among the wave's keys of the same digit (rounds before + lanes before)
@@ -102,14 +119,42 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t* _
         rnk[k] = c + before;
     }
     __syncthreads();
-    // wcnt[w][d] = the wave's total of digit d  ->  the total of the waves before it
-    for (uint32_t d = threadIdx.x; d < nd; d += kSortThreads) {
-        uint32_t run = 0u;
+    // wcnt[w][d] = the wave's total of digit d  ->  the total of the waves before it; dstart = exclusive scan of the tile's digit totals
+    {
+        constexpr uint32_t per = (nd + kSortThreads - 1) / kSortThreads;  // digits per thread (1 or 2), consecutive
+        uint32_t tot[per], mine = 0u;
 #pragma unroll
-        for (uint32_t w = 0; w < kSortWaves; ++w) {
-            const uint32_t c = wcnt[w][d];
-            wcnt[w][d] = run;
-            run += c;
+        for (uint32_t j = 0; j < per; ++j) {
+            const uint32_t d = threadIdx.x * per + j;
+            uint32_t run = 0u;
+            if (d < nd) {
+#pragma unroll
+                for (uint32_t w = 0; w < kSortWaves; ++w) {
+                    const uint32_t c = wcnt[w][d];
+                    wcnt[w][d] = run;
+                    run += c;
+                }
+            }
+            tot[j] = run;
+            mine += run;
+        }
+        uint32_t inc = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(inc, off, 64);
+            if ((int)lane >= off) inc += o;
+        }
+        if (lane == 63u) wtot[wv] = inc;
+        __syncthreads();
+        uint32_t pre = inc - mine;
+#pragma unroll
+        for (uint32_t w = 0; w < kSortWaves; ++w)
+            if (w < wv) pre += wtot[w];
+#pragma unroll
+        for (uint32_t j = 0; j < per; ++j) {
+            const uint32_t d = threadIdx.x * per + j;
+            if (d < nd) dstart[d] = pre;
+            pre += tot[j];
         }
     }
     __syncthreads();
@@ -118,7 +163,18 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t* _
         const uint64_t i = w0 + (uint64_t)k * 64u + lane;
         if (i < n) {
             const uint32_t d = (uint32_t)(key[k] >> shift) & (nd - 1u);
-            out[(uint64_t)dbase[d] + wcnt[wv][d] + rnk[k]] = key[k];
+            skey[dstart[d] + wcnt[wv][d] + rnk[k]] = key[k];
+        }
+    }
+    __syncthreads();
+    // consecutive threads, consecutive keys of the digit-ordered tile: within a run of equal digits consecutive output addresses
+#pragma unroll
+    for (uint32_t k = 0; k < kSortRounds; ++k) {
+        const uint32_t q = k * kSortThreads + threadIdx.x;
+        if (q < nvalid) {
+            const uint64_t kk = skey[q];
+            const uint32_t d = (uint32_t)(kk >> shift) & (nd - 1u);
+            out[(uint64_t)dbase[d] + (q - dstart[d])] = kk;
         }
     }
 }
