@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--cpu-runs", type=int, default=5, help="repetitions of the CPU voxelizer timings (mean and min are reported)")
     ap.add_argument("--verify-rays", type=int, default=1000)
     ap.add_argument("--big-rays", type=int, default=8_000_000, help="extra untimed-for-`value` measurement: trace throughput on a large batch (0 = skip)")
+    ap.add_argument("--pipelined-steps", type=int, default=40, help="extra untimed-for-`value` measurement: this many steps with two in flight on two streams (0 = skip)")
     ap.add_argument("--no-context", action="store_true",
                     help="skip the untimed-for-`value` context block (interior camera on this scene, BASELINE configs[1] and configs[4] trace rates)")
     ap.add_argument("--c4-grid", type=int, default=1024, help="N>1: also measure the sharded build + exchange at this resolution (0 = skip)")
@@ -441,6 +442,49 @@ def main():
         torch.cuda.synchronize()
         big = {"rays": a.big_rays, "ms": round(e0.elapsed_time(e1) / 3, 4), "mrays_per_s": round(a.big_rays * 3 / (e0.elapsed_time(e1) * 1e-3) / 1e6, 1)}
         del d_rb, d_tb, d_pb
+    # Throughput with TWO steps in flight (untimed for `value`; rank 0, N = 1): two grid handles on two HIP streams, each driven by its
+    # own host thread, every step complete and independent (its own build, list, trace and outputs).  The small latency-bound kernels at
+    # the head of a build and the drain of a ray launch leave most of the machine idle; a second step fills it.
+    piped = None
+    if rank == 0 and world == 1 and not sharded and a.pipelined_steps > 0:
+        import threading
+        streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        bufs = []
+        for k in range(2):
+            gk = voxhip.Grid.voxelize(mesh, vs, kind, stream=streams[k].cuda_stream)
+            ak = torch.empty(cap * 6, dtype=torch.float32, device=dev)
+            if kind == voxhip.GRID_VEC:
+                gk.bind_aabbs_device(ak.data_ptr(), cap)
+            bufs.append((gk, ak, torch.empty(a.rays, dtype=torch.float32, device=dev), torch.empty(a.rays, dtype=torch.int32, device=dev)))
+        torch.cuda.synchronize()
+
+        def worker(k, nsteps):
+            torch.cuda.set_device(local)
+            voxhip.set_device(local)
+            gk, ak, tk, pk = bufs[k]
+            for _ in range(nsteps):
+                gk.revoxelize(mesh, vs, stream=streams[k].cuda_stream)
+                gk.aabbs_device(ak.data_ptr(), cap)
+                gk.trace_device(d_rays.data_ptr(), a.rays, tk.data_ptr(), pk.data_ptr())
+
+        def run(nsteps):
+            th = [threading.Thread(target=worker, args=(k, nsteps)) for k in range(2)]
+            for t_ in th:
+                t_.start()
+            for t_ in th:
+                t_.join()
+            torch.cuda.synchronize()
+        run(3)
+        t0 = time.perf_counter()
+        run(a.pipelined_steps // 2)
+        dtp = time.perf_counter() - t0
+        nst = 2 * (a.pipelined_steps // 2)
+        same = bool(torch.equal(bufs[0][2], d_t) and torch.equal(bufs[1][2], d_t) and torch.equal(bufs[0][3], d_prim) and torch.equal(bufs[1][3], d_prim))
+        piped = {"what": "the same step, two in flight: two grid handles on two HIP streams, one host thread each (every step builds, lists and traces its own grid)",
+                 "steps": nst, "ms_per_step": round(dtp * 1e3 / nst, 4), "mrays_per_s": round(a.rays * nst / dtp / 1e6, 1), "outputs_equal_to_the_timed_steps": same}
+        for gk, _, _, _ in bufs:
+            gk.free()
+        del bufs
     context = None
     if rank == 0 and world == 1 and not sharded and not a.no_context and a.scene == "atrium262k":
         context = trace_context(voxhip, vx_scenes, grid, verts, vs, dev, use_oracle=not a.no_cpu_baseline)
@@ -523,7 +567,7 @@ def main():
         "stages_ms": {"voxelize": round(float(stage_ms[0]), 4), "exchange": round(float(stage_ms[1]), 4),
                       "get_aabbs": round(float(stage_ms[2]), 4), "trace": round(float(stage_ms[3]), 4)},
         "occupied_voxels": gd["occupied"], "aabbs_returned": int(nocc), "set_calls": gd["set_calls"], "ray_hits_rank0": hits,
-        "trace_large_batch": big, "trace_context": context,
+        "trace_large_batch": big, "two_steps_in_flight": piped, "trace_context": context,
         "kernel_rooflines": {k: {"achieved_GBps": round(alg_bytes[k] / (kern_all[k][0] / max(kern_all[k][1], 1) * 1e-3) / 1e9, 1),
                                  "frac_of_8TBps": round(alg_bytes[k] / (kern_all[k][0] / max(kern_all[k][1], 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
                              for k in alg_bytes if k in kern_all},

@@ -78,3 +78,23 @@ def test_contraction_on_changes_results(tmp_path, cc, reference_hashes):
     diff = {case: [k for k in keys if got[case][k] != reference_hashes[case][k]] for case in got}
     assert diff["rotcube@0.0900000036"], diff
     assert "set_calls" in diff["adversarial@0.125"], diff
+
+
+def test_oracle_under_sanitizers(tmp_path, golden):
+    """The checker under AddressSanitizer + UndefinedBehaviorSanitizer (CPU build only: the GPU pool has no sanitizer runs): the
+    regression cases run clean and give the committed hashes."""
+    asan, ubsan = (subprocess.check_output(["gcc", "-print-file-name=" + n]).decode().strip() for n in ("libasan.so", "libubsan.so"))
+    if not (os.path.isabs(asan) and os.path.exists(asan) and os.path.isabs(ubsan) and os.path.exists(ubsan)):
+        pytest.skip("gcc sanitizer runtimes not installed")
+    so = os.path.join(str(tmp_path), "libvxoracle_san.so")
+    subprocess.check_call(["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-ffp-contract=off"] + BASE +
+                          ["-o", so, os.path.join(ORACLE, "vx_oracle.c"), os.path.join(ORACLE, "vx_walk.c"), "-lm", "-lpthread"])
+    env = dict(os.environ, VXORACLE_SO=so, LD_PRELOAD=asan + ":" + ubsan, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([sys.executable, os.path.join(GOLD, "hash_cases.py")], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-2000:]
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    for case, h in got.items():
+        if case in golden:
+            for k in ("words_sha", "aabbs_sha", "vec_sha", "octree_items_sha", "octree_nodes_sha", "set_calls"):
+                assert h[k] == golden[case][k], (case, k)
