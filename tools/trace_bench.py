@@ -31,4 +31,18 @@ for n in sizes:
         ot, op = oracle.trace_brute(oa, rays_h[sel])
         tt, pp = d_t.cpu().numpy()[sel], d_p.cpu().numpy().view(np.uint32)[sel]
         out.append("check: %s" % ("ok" if (np.array_equal(tt, ot) and np.array_equal(pp, op)) else "MISMATCH %d" % int((tt != ot).sum())))
+if os.environ.get("TB_INTERIOR"):
+    W, H = 1280, 720
+    d_t = torch.empty(W * H, dtype=torch.float32, device="cuda"); d_p = torch.empty(W * H, dtype=torch.int32, device="cuda")
+    ms = 0.0
+    for cam in vx_scenes.INTERIOR_CAMERAS:
+        vi, pi = vx_scenes.camera_matrices(**cam)
+        g.trace_primary_device(vi, pi, W, H, d_t.data_ptr(), d_p.data_ptr()); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            g.trace_primary_device(vi, pi, W, H, d_t.data_ptr(), d_p.data_ptr())
+        e1.record(); torch.cuda.synchronize()
+        ms += e0.elapsed_time(e1) / 5
+    out.append("interior 2x%dx%d: %.4f ms (%.0f Mrays/s)" % (W, H, ms, 2 * W * H / ms / 1e3))
 print(" | ".join(out))
