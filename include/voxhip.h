@@ -271,6 +271,10 @@ typedef struct vx_trace_args {
 vx_status vx_trace_ex_device(const vx_grid* g, const vx_trace_args* args);
 vx_status vx_trace_ex(const vx_grid* g, const vx_trace_args* args);
 
+/* ---- test aid: the device radix sort the Octree uses for its Morton items (octTree.hpp:363 -> vx_sort.hip), applied to a host array.
+ * Keys must have no bit set at or above `bits` (1..64); sorted in place. */
+vx_status vx_sort_u64(uint64_t* host_keys, uint64_t n, int bits);
+
 /* ---- measurement aid: per-kernel durations from HIP events recorded on the launch stream (off by default).
  * slot = 0,1,... until VX_ERR_INVALID_ARG; name is the kernel symbol as launched. */
 vx_status vx_profile_enable(int on);

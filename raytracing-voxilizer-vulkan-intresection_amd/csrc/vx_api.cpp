@@ -1886,6 +1886,33 @@ void vx_octree_free(vx_octree* o)
     delete o;
 }
 
+// ---- test aid: the octree's item sort on a host array ----------------------------------------------------------
+vx_status vx_sort_u64(uint64_t* host_keys, uint64_t n, int bits)
+{
+    if (!host_keys && n) return fail(VX_ERR_INVALID_ARG, "null argument");
+    if (bits < 1 || bits > 64) return fail(VX_ERR_INVALID_ARG, "bits must be in 1..64");
+    if (n >= 0xFFFFFFFFull) return fail(VX_ERR_CAPACITY, "more than 2^32 keys");
+    if (!n) return VX_OK;
+    VX_TRY(need_device(g_device));
+    DeviceGuard dg(g_device);
+    DevBuf a, b, tmp;
+    for (DevBuf* x : {&a, &b, &tmp}) x->dev = g_device;
+    auto rel = [&]() { for (DevBuf* x : {&a, &b, &tmp}) x->release(false); };
+    hipError_t e = a.ensure((size_t)n * 8);
+    if (e == hipSuccess) e = b.ensure((size_t)n * 8);
+    const size_t tb = vx::sort_tmp_bytes(n);
+    if (e == hipSuccess) e = tmp.ensure(tb);
+    if (e == hipSuccess) e = hipMemcpy(a.p, host_keys, (size_t)n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        const int where = vx::launch_sort_u64(a.as<uint64_t>(), b.as<uint64_t>(), n, bits, tmp.p, tb, nullptr);
+        e = hipStreamSynchronize(nullptr);
+        if (e == hipSuccess) e = hipMemcpy(host_keys, where == 0 ? a.p : b.p, (size_t)n * 8, hipMemcpyDeviceToHost);
+    }
+    rel();
+    VX_HIP(e);
+    return VX_OK;
+}
+
 // ---- per-kernel timing (bench / profiling aid) ----------------------------------------------------------------
 vx_status vx_profile_enable(int on)
 {

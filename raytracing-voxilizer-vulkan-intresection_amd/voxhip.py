@@ -60,7 +60,7 @@ SYMBOLS = [
     "vx_grid_create", "vx_grid_describe", "vx_grid_set_voxel", "vx_grid_test_voxel", "vx_grid_coords", "vx_grid_bytes",
     "vx_grid_bitmask", "vx_grid_bitmask_device", "vx_grid_bitmask_device_mut", "vx_grid_refresh", "vx_grid_aabbs",
     "vx_grid_aabbs_device", "vx_grid_bind_aabbs_device", "vx_grid_materials", "vx_grid_material_ids", "vx_grid_material_ids_device", "vx_grid_material_first_use",
-    "vx_grid_finish_materials", "vx_multi_create", "vx_multi_voxelize", "vx_multi_grid", "vx_multi_release_grid", "vx_multi_free", "vx_grid_free",
+    "vx_grid_finish_materials", "vx_multi_create", "vx_multi_voxelize", "vx_multi_grid", "vx_multi_release_grid", "vx_multi_free", "vx_sort_u64", "vx_grid_free",
     "vx_octree_build", "vx_octree_num_items", "vx_octree_num_nodes", "vx_octree_bytes", "vx_octree_items", "vx_octree_nodes",
     "vx_octree_root_bounds", "vx_octree_aabbs", "vx_octree_aabbs_device", "vx_octree_free",
     "vx_trace", "vx_trace_device", "vx_trace_primary_device", "vx_trace_ex", "vx_trace_ex_device",
@@ -132,6 +132,7 @@ def lib():
     L.vx_voxelize.argtypes = [vp, C.c_float, C.c_int, C.POINTER(VoxelizeOpts), C.POINTER(vp)]
     L.vx_voxelize_into.argtypes = [vp, C.c_float, C.POINTER(VoxelizeOpts), vp]
     L.vx_voxelize_multi.argtypes = [vp, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(vp)]
+    L.vx_sort_u64.argtypes = [vp, C.c_uint64, C.c_int]
     L.vx_multi_create.argtypes = [vp, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(vp)]
     L.vx_multi_voxelize.argtypes = [vp, C.c_float, vp, C.c_int]
     L.vx_multi_grid.argtypes = [vp, C.c_int]
@@ -504,6 +505,13 @@ class Grid:
             self.free()
         except Exception:
             pass
+
+
+def sort_u64(keys, bits):
+    """vx_sort_u64: the octree's device radix sort on a host array (returns a sorted copy)."""
+    k = np.ascontiguousarray(keys, dtype=np.uint64).copy()
+    _check(lib().vx_sort_u64(k.ctypes.data, k.size, int(bits)))
+    return k
 
 
 class BorrowedGrid(Grid):

@@ -119,6 +119,23 @@ def test_octree_node_array_large(gpu, ntri, grid, max_items):
     assert o.memory_bytes() == 8 * len(oitems) + 40 * len(ref)
 
 
+@pytest.mark.parametrize("bits", [1, 5, 8, 9, 10, 18, 33, 48, 63, 64])
+def test_item_sort_direct(gpu, bits):
+    """vx_sort.hip (replaces std::sort(par_unseq), octTree.hpp:363) on its own: every pass count (1..8 digits of 8-9 bits), sizes
+    around the 4096-key tile, heavy duplicates, already sorted and reversed input -- against numpy's sort."""
+    rng = np.random.default_rng(bits)
+    hi = (1 << bits) - 1
+    for n in (0, 1, 2, 63, 64, 65, 4095, 4096, 4097, 12289, 100_003, 2_500_000):
+        k = rng.integers(0, hi, n, dtype=np.uint64, endpoint=True)
+        if n > 1000:
+            k[rng.integers(0, n, n // 3)] = k[0]                # a third of the keys identical
+            k[rng.integers(0, n, n // 10)] = np.uint64(hi)      # ... and many at the upper end
+        assert np.array_equal(gpu.sort_u64(k, bits), np.sort(k)), (bits, n)
+    k = np.arange(50_000, dtype=np.uint64) & np.uint64(hi)
+    assert np.array_equal(gpu.sort_u64(k, bits), np.sort(k))
+    assert np.array_equal(gpu.sort_u64(k[::-1], bits), np.sort(k))
+
+
 def long_thin_mesh(ncells=100_000, ntri=4000, seed=9):
     """A mesh 100 000 x 8 x 8 voxels long (voxel size 1): small triangles all along x, a few long ones spanning > 65535 cells."""
     rng = np.random.default_rng(seed)
