@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_round
 rm -rf $O && mkdir -p $O
-BENCH="python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --big-rays 0 --no-context"
+BENCH="python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --big-rays 0 --no-context --pipelined-steps 0"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- $BENCH > $O/kt.log 2>&1 || echo "kernel trace failed"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -o pmc -- $BENCH > $O/pmc_$c.log 2>&1 || echo "pmc $c failed"
