@@ -101,7 +101,7 @@ def test_octree(gpu, name, vs, max_items):
 
 
 @pytest.mark.parametrize("ntri,grid,max_items", [(20000, 256, 16), (200000, 512, 16), (200000, 512, 3), (60000, 256, 64), (60000, 256, 65),
-                                                 (60000, 256, 1000)])
+                                                 (60000, 256, 1000), (20000, 128, 0), (5000, 64, 2), (3000, 16, 16), (40000, 256, 10 ** 9)])
 def test_octree_node_array_large(gpu, ntri, grid, max_items):
     """Octree node arrays of 10^5 .. 10^6 items (the direct node build's galloping searches cross many workgroups; max_items <= 64
     takes the direct form, larger values the level-by-level form): items and all 40-byte nodes against Octree::buildNodeRecursive
