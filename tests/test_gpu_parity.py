@@ -850,6 +850,16 @@ def test_multi_context_steady_state(gpu):
         ot, op = oracle.trace_brute(oa, rays)
         assert np.array_equal(tt, ot) and np.array_equal(pp, op)
     mc.free()
+    # error paths: an unknown device, a flavour whose order needs triangle shards, a borrowed (device-only) mesh
+    with pytest.raises(gpu.VxError):
+        gpu.Multi(mesh, [0, 99])
+    with pytest.raises(gpu.VxError) as ei:
+        gpu.Multi(mesh, [0, 0], kind=gpu.GRID_VEC)
+    assert ei.value.status == 9
+    import torch
+    dv, dt_ = torch.from_numpy(v).cuda(), torch.from_numpy(t).cuda()
+    with pytest.raises(gpu.VxError):
+        gpu.Multi(gpu.Mesh.from_device(dv.data_ptr(), len(v), dt_.data_ptr(), len(t), keep=(dv, dt_)), [0, 0])
 
 
 # ---------------------------------------------------------------------------------------------- multi-GPU entry of the C ABI
