@@ -115,6 +115,15 @@ __global__ __launch_bounds__(256) void k_oct_nodes(const uint64_t* __restrict__ 
         nlive += (uint32_t)__popcll(m);
     }
     // (a wave's LDS writes are visible to its own later reads: no barrier)
+    // The DEEPEST node of a position is a leaf (a child would start at the same position, one level deeper), no node starts inside
+    // a leaf, and every node ends where another one starts: a leaf's run ends at the next position that starts nodes -- the next
+    // entry of the list; for the stretch's last entry the first such position behind the stretch (n when there is none).
+    uint32_t next_after = n;
+    for (uint64_t q0 = p0 + kNodeStretch; q0 < n; q0 += 64u) {
+        const uint64_t p = q0 + lane;
+        const unsigned long long m = __ballot(p < n && base[p + 1u] != base[p]);
+        if (m) { next_after = (uint32_t)(q0 + (uint64_t)(__ffsll((long long)m) - 1)); break; }
+    }
   for (uint32_t e = lane; e < nlive; e += 64u) {
     const uint32_t i = live[wv][e];
     const uint32_t b0 = base[i], nn = base[i + 1u] - b0;
@@ -129,16 +138,20 @@ __global__ __launch_bounds__(256) void k_oct_nodes(const uint64_t* __restrict__ 
         // inside the end of the shallower run.  Galloping search from i: runs are short as a rule.
         int64_t lo = (int64_t)i;   // prefix(item[lo]) == pref
         int64_t hi = end_prev;     // prefix(item[hi]) > pref, or hi == the shallower run's end
+        if (q + 1u == nn) {
+            hi = (int64_t)(e + 1u < nlive ? live[wv][e + 1u] : next_after);  // the leaf: no search
+        } else {
 #pragma nounroll
-        for (int64_t step = 1; (int64_t)i + step < hi; step <<= 1) {
-            const int64_t p = (int64_t)i + step;
-            if ((items[p] >> shift) > pref) { hi = p; break; }
-            lo = p;
-        }
+            for (int64_t step = 1; (int64_t)i + step < hi; step <<= 1) {
+                const int64_t p = (int64_t)i + step;
+                if ((items[p] >> shift) > pref) { hi = p; break; }
+                lo = p;
+            }
 #pragma nounroll
-        while (hi - lo > 1) {
-            const int64_t mid = lo + ((hi - lo) >> 1);
-            if ((items[mid] >> shift) > pref) hi = mid; else lo = mid;
+            while (hi - lo > 1) {
+                const int64_t mid = lo + ((hi - lo) >> 1);
+                if ((items[mid] >> shift) > pref) hi = mid; else lo = mid;
+            }
         }
         const uint32_t id = b0 + q;
         nodes[id].start = i;          // octTree.hpp:325-327
