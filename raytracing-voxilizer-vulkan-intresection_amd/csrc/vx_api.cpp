@@ -303,7 +303,7 @@ struct vx_grid {
     float bbmin[3] = {0, 0, 0}, bbmax[3] = {0, 0, 0}, bbc[3] = {0, 0, 0};
     uint64_t triangles = 0;
     uint32_t cdim[3] = {0, 0, 0}, c2dim[3] = {0, 0, 0};
-    DevBuf words, cwords, c2words, bricks, idxtmp, ttmp, camera, wprefix, wsel /*word of every 1024th occupied voxel (prefix scan)*/, recs, ext /*high bits of the candidate ranges*/, units, ubase, btri, umask, hbase, scantmp, small, vec, matids, mattmp;
+    DevBuf words, twords /*tiled build mask (launch_voxelize)*/, cwords, c2words, bricks, idxtmp, ttmp, camera, wprefix, wsel /*word of every 1024th occupied voxel (prefix scan)*/, recs, ext /*high bits of the candidate ranges*/, units, ubase, btri, umask, bhits /*hits per block of 64 units*/, hbase /*their exclusive scan*/, scantmp, small, vec, matids, mattmp;
     std::vector<vx_material> materials;  // m_materials: distinct values in first-use order (VX_VOXELIZE_MATERIALS builds only)
     uint64_t mat_count = 0;              // entries of matids
     bool has_materials = false;
@@ -318,6 +318,7 @@ struct vx_grid {
     bool mat_gathered = false;             // multi-GPU build: the ids of ALL shards, gathered in shard order, live in mattmp
     uint64_t mat_gather_count = 0;
     bool coarse_valid = false, prefix_valid = false /*word_prefix queued or done*/, occupied_known = false, counts_valid = true;
+    bool last_tiled = false;  // the previous build on this handle went through the tiled build mask (twords)
     uint64_t occupied = 0, set_calls = 0, host_set_calls = 0;
     uint64_t vec_count = 0;
     uint32_t mail_seq = 0;  // sequence tag of the totals the current build writes to the mailbox
@@ -333,18 +334,18 @@ struct vx_grid {
     void set_dev(int d)
     {
         device = d;
-        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &idxtmp, &ttmp, &camera, &wprefix, &wsel, &recs, &ext, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec, &matids, &mattmp}) b->dev = d;
+        for (DevBuf* b : {&words, &twords, &cwords, &c2words, &bricks, &idxtmp, &ttmp, &camera, &wprefix, &wsel, &recs, &ext, &units, &ubase, &btri, &umask, &bhits, &hbase, &scantmp, &small, &vec, &matids, &mattmp}) b->dev = d;
     }
     // the stream this handle queues work on; the pool orders the reuse of released blocks by it
     void set_stream(hipStream_t st)
     {
         if (st != stream && words.p) (void)hipStreamSynchronize(stream);  // work queued on the old stream must not outlive the switch
         stream = st;
-        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &idxtmp, &ttmp, &camera, &wprefix, &wsel, &recs, &ext, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec, &matids, &mattmp}) b->stream = st;
+        for (DevBuf* b : {&words, &twords, &cwords, &c2words, &bricks, &idxtmp, &ttmp, &camera, &wprefix, &wsel, &recs, &ext, &units, &ubase, &btri, &umask, &bhits, &hbase, &scantmp, &small, &vec, &matids, &mattmp}) b->stream = st;
     }
     void release_all()
     {
-        for (DevBuf* b : {&words, &cwords, &c2words, &bricks, &idxtmp, &ttmp, &camera, &wprefix, &wsel, &recs, &ext, &units, &ubase, &btri, &umask, &hbase, &scantmp, &small, &vec, &matids, &mattmp}) b->release();
+        for (DevBuf* b : {&words, &twords, &cwords, &c2words, &bricks, &idxtmp, &ttmp, &camera, &wprefix, &wsel, &recs, &ext, &units, &ubase, &btri, &umask, &bhits, &hbase, &scantmp, &small, &vec, &matids, &mattmp}) b->release();
         if (mail) (void)hipHostFree(mail);
         mail = nullptr;
     }
@@ -843,7 +844,8 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
     Extent ex;
     uint64_t btri_entries = 0;  // entries of the block table filled by the launch queued ahead of the unit total
     bool setup_queued = false;
-    size_t cleared = 0;
+    size_t cleared = 0;         // bytes of the build's mask cleared ahead of the host wait ...
+    bool cleared_tiled = false;  // ... of the tiled build mask, that is
     if (ntri > 0) {  // (a word shard's z slab is derived from the device-side dims by the record kernel itself)
         vx::GridParams gp{};
         const float zero3[3] = {0.f, 0.f, 0.f};
@@ -853,11 +855,14 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
         bool units_tagged = false;
         // the previous build's bitmask is cleared in the same window -- by the record kernel's own threads when there are enough of
         // them (at most 256 bytes each), by a memset behind the block table otherwise
-        const bool clear_in_setup = g->words.p && (g->words.cap % 16) == 0 && g->words.cap / 256 <= (size_t)ntri;
+        // (a handle whose previous build went through the tiled build mask is expected to do so again: that is the buffer to clear)
+        DevBuf& cb = (g->last_tiled && g->twords.p) ? g->twords : g->words;
+        cleared_tiled = &cb == &g->twords;
+        const bool clear_in_setup = cb.p && (cb.cap % 16) == 0 && cb.cap / 256 <= (size_t)ntri;
         VX_TRY(setup_launch(mesh, gp, o.sat_variant, tb, ntri, 0, 0, g->recs, g->units, g->ubase, g->scantmp, g->mail, s, g->ext, &ds->dgrid, mtag, &units_tagged,
-                            clear_in_setup ? g->words.p : nullptr, clear_in_setup ? g->words.cap : 0, sharded_words ? o.word_begin : 0,
+                            clear_in_setup ? cb.p : nullptr, clear_in_setup ? cb.cap : 0, sharded_words ? o.word_begin : 0,
                             sharded_words ? o.word_end : 0, by_rank ? (uint32_t)o.shard_rank : 0u, by_rank ? (uint32_t)o.shard_world : 0u));
-        if (clear_in_setup) cleared = g->words.cap;
+        if (clear_in_setup) cleared = cb.cap;
         // the block table of the units: queued now, for as many blocks as the handle's table from the previous build holds, so that
         // it runs while the host waits for the unit total (redone by setup_finish should the table turn out too small)
         if (g->btri.p && g->btri.cap >= 64) {
@@ -865,9 +870,9 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
             if (btri_entries > 0x3FFFFFFull) btri_entries = 0x3FFFFFFull;
             vx::launch_unit_blocks(g->ubase.as<uint32_t>(), ntri, (uint32_t)((btri_entries - 2) * 64), g->btri.as<uint32_t>(), s, (uint32_t)btri_entries);
         }
-        if (g->words.p && !clear_in_setup) {
-            VX_HIP(hipMemsetAsync(g->words.p, 0, g->words.cap, s));
-            cleared = g->words.cap;
+        if (cb.p && !clear_in_setup) {
+            VX_HIP(hipMemsetAsync(cb.p, 0, cb.cap, s));
+            cleared = cb.cap;
         }
         // the bbox (written by k_bbox, two kernels earlier) and the unit total: polled from the mailbox, see the hit count below
         if (!(poll_mail && units_tagged && mail_wait(&g->mail->units, nullptr, mtag, 5.0))) VX_HIP(hipStreamSynchronize(s));
@@ -882,8 +887,9 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
     for (int a = 0; a < 3; ++a) { g->bbmin[a] = ex.mn[a]; g->bbmax[a] = ex.mx[a]; g->bbc[a] = ex.ctr[a]; }
     VX_TRY(init_grid_storage(g, /*clear=*/false));
     const size_t mask_bytes = (size_t)(g->g.nwords + 2) * 4;
-    if (g->words.fresh) { cleared = 0; g->words.fresh = false; }  // a new block: the early clear hit the old one
-    const bool mask_is_clear = cleared >= mask_bytes;
+    const bool words_fresh = g->words.fresh;
+    if (g->words.fresh) { if (!cleared_tiled) cleared = 0; g->words.fresh = false; }  // a new block: the early clear hit the old one
+    bool mask_is_clear = !cleared_tiled && cleared >= mask_bytes;
 
     uint64_t wb = 0, we = g->g.nwords;
     if (by_rank) {
@@ -910,6 +916,20 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
         return no_calls_materials();
     }
 
+    // Unsharded words, rows of whole words: the voxelizer ORs into the tiled build mask (one atomic request per 4 x 4 rows instead of one per
+    // row, launch_voxelize) and launch_untile writes every word of the reference's bitmask from it.  VOXHIP_VOX_TILED=0: always the direct form.
+    static const bool tiled_ok = !(getenv("VOXHIP_VOX_TILED") && atoi(getenv("VOXHIP_VOX_TILED")) == 0);
+    const bool tiled = tiled_ok && wb == 0 && we == g->g.nwords && (ex.dim[0] % 32) == 0;
+    g->last_tiled = tiled;
+    if (tiled) {
+        const size_t tbytes = (size_t)vx::tiled_mask_words(g->g.dim) * 4;
+        VX_HIP(g->twords.ensure(tbytes));
+        const bool tw_clear = cleared_tiled && cleared >= tbytes && !g->twords.fresh;
+        g->twords.fresh = false;
+        if (!tw_clear) VX_HIP(hipMemsetAsync(g->twords.p, 0, tbytes, s));
+        if (words_fresh) VX_HIP(hipMemsetAsync(g->words.p, 0, mask_bytes, s));  // (the two words behind the mask)
+        mask_is_clear = true;  // every word of the mask is written by launch_untile
+    }
     uint64_t U = 0;
     if (setup_queued) {
         if (!mask_is_clear) VX_HIP(hipMemsetAsync(g->words.p, 0, mask_bytes, s));
@@ -934,15 +954,23 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
     }
     // an axis above 65535 cells: the unit kernels also read the extension words of the candidate ranges
     const uint32_t* xw = (ex.dim[0] > 65535 || ex.dim[1] > 65535 || ex.dim[2] > 65535) ? g->ext.as<uint32_t>() : nullptr;
+    // VoxelGridVec::setVoxel appends one Aabb per call (voxelgridVecEncoding.cpp:19-39): ordered emission, at the exclusive scan of the
+    // hit counts -- two-level: the voxelizer leaves the hits of every block of 64 units, the device scan runs over those
+    const uint64_t nUB = (U + 63) / 64;
+    uint32_t* bhits = nullptr;
+    if (g->kind == VX_GRID_VEC) {
+        VX_HIP(g->bhits.ensure((size_t)(nUB + 4) * 4));
+        VX_HIP(g->hbase.ensure((size_t)(nUB + 4) * 4));
+        bhits = g->bhits.as<uint32_t>();
+    }
     vx::launch_voxelize(g->recs.as<vx::TriRec>(), g->ubase.as<uint32_t>(), g->btri.as<uint32_t>(), ntri, g->g, o.sat_variant,
-                        g->words.as<uint32_t>(), wb, we, umask, ds->set_calls, s, xw);
+                        tiled ? g->twords.as<uint32_t>() : g->words.as<uint32_t>(), wb, we, umask, ds->set_calls, s, xw, bhits, tiled);
+    if (tiled) vx::launch_untile(g->twords.as<uint32_t>(), g->words.as<uint32_t>(), g->g.dim, s);
     g->counts_valid = false;
     bool hits_tagged = false, occ_tagged = false, occ_queued = false;
     if (g->kind == VX_GRID_VEC) {
-        // VoxelGridVec::setVoxel appends one Aabb per call (voxelgridVecEncoding.cpp:19-39): ordered emission
-        VX_HIP(g->hbase.ensure((size_t)(U + 2) * 4));
-        VX_HIP(ensure_scan_tmp(g->scantmp, vx::scan_tmp_bytes(U), s));
-        hits_tagged = vx::launch_scan_u32(umask, g->hbase.as<uint32_t>(), U, true, g->scantmp.p, &g->mail->hits, s, true, mtag, nullptr, next_scan_gen(g->scantmp, s));
+        VX_HIP(ensure_scan_tmp(g->scantmp, vx::scan_tmp_bytes(nUB), s));
+        hits_tagged = vx::launch_scan_u32(bhits, g->hbase.as<uint32_t>(), nUB, false, g->scantmp.p, &g->mail->hits, s, true, mtag, nullptr, next_scan_gen(g->scantmp, s));
     }
     // A complete (unsharded) bitmask: queue what every consumer of the grid needs next -- the traversal structure (bricks,
     // bounds, mips = the reference's acceleration-structure build, hello_vulkan.cpp:700-703) and the word prefix (getAabbs /
@@ -1723,11 +1751,11 @@ vx_status vx_octree_build(const vx_mesh* mesh_c, float vs, uint64_t max_items, v
     o->max_items = max_items;
     o->items.dev = o->nodebuf.dev = o->device;
     o->items.stream = o->nodebuf.stream = s;
-    DevBuf small, recs, ext, units, ubase, btri, scantmp, umask, hbase, unsorted, sorttmp, ncount, nbase;
-    for (DevBuf* b : {&small, &recs, &ext, &units, &ubase, &btri, &scantmp, &umask, &hbase, &unsorted, &sorttmp, &ncount, &nbase}) { b->dev = o->device; b->stream = s; }
+    DevBuf small, recs, ext, units, ubase, btri, scantmp, umask, bhits, hbase, unsorted, sorttmp, ncount, nbase;
+    for (DevBuf* b : {&small, &recs, &ext, &units, &ubase, &btri, &scantmp, &umask, &bhits, &hbase, &unsorted, &sorttmp, &ncount, &nbase}) { b->dev = o->device; b->stream = s; }
     Mail* mail = nullptr;
     auto cleanup = [&]() {
-        for (DevBuf* b : {&small, &recs, &ext, &units, &ubase, &btri, &scantmp, &umask, &hbase, &unsorted, &sorttmp, &ncount, &nbase}) b->release();
+        for (DevBuf* b : {&small, &recs, &ext, &units, &ubase, &btri, &scantmp, &umask, &bhits, &hbase, &unsorted, &sorttmp, &ncount, &nbase}) b->release();
         if (mail) (void)hipHostFree(mail);
         mail = nullptr;
     };
@@ -1758,10 +1786,13 @@ vx_status vx_octree_build(const vx_mesh* mesh_c, float vs, uint64_t max_items, v
     unsigned long long hits = 0;
     if (U) {
         OCT_HIP(umask.ensure((size_t)(U + 1) * 4));
-        OCT_HIP(hbase.ensure((size_t)(U + 2) * 4));
-        OCT_HIP(ensure_scan_tmp(scantmp, vx::scan_tmp_bytes(U), s));
-        vx::launch_voxelize(recs.as<vx::TriRec>(), ubase.as<uint32_t>(), btri.as<uint32_t>(), ntri, g, 0, nullptr, 0, 0, umask.as<uint32_t>(), ds->set_calls, s, xw);
-        vx::launch_scan_u32(umask.as<uint32_t>(), hbase.as<uint32_t>(), U, true, scantmp.p, &mail->hits, s, true, 0, nullptr, next_scan_gen(scantmp, s));
+        const uint64_t nUB = (U + 63) / 64;  // hits per block of 64 units from the voxelizer, scanned: the items' positions (as for the Vec grid)
+        OCT_HIP(bhits.ensure((size_t)(nUB + 4) * 4));
+        OCT_HIP(hbase.ensure((size_t)(nUB + 4) * 4));
+        OCT_HIP(ensure_scan_tmp(scantmp, vx::scan_tmp_bytes(nUB), s));
+        vx::launch_voxelize(recs.as<vx::TriRec>(), ubase.as<uint32_t>(), btri.as<uint32_t>(), ntri, g, 0, nullptr, 0, 0, umask.as<uint32_t>(), ds->set_calls, s, xw,
+                            bhits.as<uint32_t>());
+        vx::launch_scan_u32(bhits.as<uint32_t>(), hbase.as<uint32_t>(), nUB, false, scantmp.p, &mail->hits, s, true, 0, nullptr, next_scan_gen(scantmp, s));
         OCT_HIP(hipStreamSynchronize(s));
         hits = mail->hits & kMailValue;
         if (hits >= 0xFFFFFFFFull) return bail(fail(VX_ERR_CAPACITY, "more than 2^32 octree items"));

@@ -85,11 +85,18 @@ void launch_scan_u8(const uint8_t* in, uint32_t* out, uint64_t n, void* tmp /*sc
 void launch_unit_blocks(const uint32_t* unit_base, uint32_t ntri, uint32_t total_units, uint32_t* block_tri, hipStream_t s, uint32_t cap_blocks = 0xFFFFFFFFu);
 void launch_voxelize(const TriRec* recs, const uint32_t* unit_base, const uint32_t* block_tri, uint32_t ntri, const GridParams& g,
                      int sat_variant, uint32_t* words, uint64_t wb, uint64_t we, uint32_t* unit_mask, unsigned long long* set_calls,
-                     hipStream_t s, const uint32_t* ext = nullptr /*k_tri_setup's extension words; null unless an axis has more than 65535 cells*/);
+                     hipStream_t s, const uint32_t* ext = nullptr /*k_tri_setup's extension words; null unless an axis has more than 65535 cells*/,
+                     uint32_t* block_hits = nullptr /*with unit_mask: hits per block of 64 units, (U + 63) / 64 entries -- what launch_emit_units'
+                                                      block_base is the exclusive scan of*/,
+                     bool tiled = false /*`words` is the tiled build mask (tiled_mask_words(dim) words, dim[0] % 32 == 0, whole grid): launch_untile
+                                          then writes the reference's bitmask*/);
+uint64_t tiled_mask_words(const uint32_t dim[3]);
+void launch_untile(const uint32_t* tiled, uint32_t* words, const uint32_t dim[3], hipStream_t s);
 
-// K3: VoxelGridVec / Octree emitters: one output per set bit of unit_mask, in unit order (== reference order).
+// K3: VoxelGridVec / Octree emitters: one output per set bit of unit_mask, in unit order (== reference order).  block_base[b] = position of
+// the first hit of units [64 b, 64 b + 64): the exclusive scan of launch_voxelize's block_hits.
 void launch_emit_units(const TriRec* recs, const uint32_t* unit_base, const uint32_t* block_tri, uint32_t ntri, const GridParams& g,
-                       const uint32_t* unit_mask, const uint32_t* hit_base, vx_aabb* aabbs, uint64_t* morton, hipStream_t s, uint64_t cap = ~0ull,
+                       const uint32_t* unit_mask, const uint32_t* block_base, vx_aabb* aabbs, uint64_t* morton, hipStream_t s, uint64_t cap = ~0ull,
                        const uint32_t* ext = nullptr);
 
 // Per-voxel material ids (the reference's commented-out addMatrialIfNeeded plumbing): pass 1 = last triangle per occupied voxel
@@ -99,7 +106,7 @@ void launch_mat_last(const TriRec* recs, const uint32_t* unit_base, const uint32
                      const uint32_t* words, const uint32_t* word_prefix, uint32_t* last_tri, uint8_t* tri_hit, hipStream_t s, const uint32_t* ext = nullptr);
 void launch_mat_ids(const uint32_t* last_tri, uint64_t n, const int32_t* tri_value, const int16_t* value_index, int16_t* out, hipStream_t s);
 void launch_mat_ids_calls(const TriRec* recs, const uint32_t* unit_base, const uint32_t* block_tri, uint32_t ntri, const uint32_t* unit_mask,
-                          const uint32_t* hit_base, const int32_t* tri_value, const int16_t* value_index, int16_t* out, hipStream_t s);
+                          const uint32_t* block_base, const int32_t* tri_value, const int16_t* value_index, int16_t* out, hipStream_t s);
 
 // K4: bitmask -> ordered AABB list (word_prefix = exclusive scan of popcounts, nwords+1 entries)
 void launch_emit_bool_aabbs(const uint32_t* words, const uint32_t* word_prefix, const GridParams& g, vx_aabb* out,

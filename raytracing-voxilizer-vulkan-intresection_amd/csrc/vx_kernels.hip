@@ -292,7 +292,10 @@ constexpr unsigned long long kScanFlagA = 1ull << 62, kScanFlagP = 2ull << 62, k
 //     buffer reads as "not there yet", so nothing has to be cleaned up -- the finished-tiles counter, its returning atomic and the
 //     zeroing loop are gone as well.  The caller numbers the scans of a buffer 1, 2, 3, ... (and clears the buffer when the number
 //     wraps at 2^22); a buffer fresh from the allocator is cleared once.
-constexpr uint32_t kScanGenTiles = 512;
+#ifndef VX_SCAN_GEN_TILES
+#define VX_SCAN_GEN_TILES 512
+#endif
+constexpr uint32_t kScanGenTiles = VX_SCAN_GEN_TILES;
 constexpr unsigned long long kScanGenValMask = (1ull << 40) - 1ull;
 
 // Large tiles (1024 threads x 16 elements): a 4M-element scan is 256 tiles, so the look-back chain is a handful of hops
@@ -624,6 +627,18 @@ __device__ __forceinline__ uint32_t find_tri(const uint32_t* __restrict__ unit_b
     return lo;
 }
 
+// a / b for the unit decode, a < 2^22, 1 <= b < 2^24.  The compiler's 32-bit division is ~20 instructions, four of them quarter-rate
+// multiplies, and a unit needs two; here the float quotient a * rcp(b) is within one of the true one (relative error < 2^-22),
+// which one 24-bit multiply-subtract tells and repairs.
+__device__ __forceinline__ uint32_t udiv_unit(uint32_t a, uint32_t b)
+{
+    uint32_t q = (uint32_t)((float)a * __builtin_amdgcn_rcpf((float)b));
+    const int rem = (int)a - (int)__umul24(q, b);  // q <= a / b + 1: q * b <= a + b fits easily
+    if (rem < 0) --q;
+    else if (rem >= (int)b) ++q;
+    return q;
+}
+
 // e: the triangle's extension word (k_tri_setup), 0 for grids without an axis above 65535 cells
 __device__ __forceinline__ Unit decode_unit(const TriRec& r, uint32_t tri, uint32_t rel, uint32_t e = 0u)
 {
@@ -634,8 +649,19 @@ __device__ __forceinline__ Unit decode_unit(const TriRec& r, uint32_t tri, uint3
     const uint32_t zs = (r.zr & 0xFFFFu) | (((e >> 20) & 31u) << 16);
     const uint32_t seg0 = xs >> 5;
     const uint32_t nseg = ((xs + nx - 1u) >> 5) - seg0 + 1u;
-    const uint32_t row = rel / nseg, sx = rel - row * nseg;
-    const uint32_t zz = row / ny, yy = row - zz * ny;
+    uint32_t row, sx, zz, yy;
+#ifndef VX_UNIT_INT_DIV
+    if (rel < (1u << 22)) {  // every triangle but the wall-sized ones of the largest grids (nseg <= 2^16, ny <= 2^21)
+        row = nseg == 1u ? rel : udiv_unit(rel, nseg);
+        sx = rel - __umul24(row, nseg);
+        zz = udiv_unit(row, ny);
+        yy = row - __umul24(zz, ny);
+    } else
+#endif
+    {
+        row = rel / nseg; sx = rel - row * nseg;
+        zz = row / ny; yy = row - zz * ny;
+    }
     w.xseg = (seg0 + sx) << 5;
     w.x0 = xs > w.xseg ? xs : w.xseg;
     const uint32_t xe = xs + nx, se = w.xseg + 32u;
@@ -719,6 +745,9 @@ constexpr uint32_t kStagesPerBlock = 2 * 4;  // double-buffered, four waves per 
 #define VX_UNIT_BLOCKS (256 * 6)
 #endif
 constexpr unsigned kUnitBlocks = VX_UNIT_BLOCKS;
+#ifndef VX_EMIT_BLOCKS
+#define VX_EMIT_BLOCKS (2u * kMaxBlocks)
+#endif
 
 // Asynchronous global -> LDS copies (gfx950 LDS-DMA: no VGPR destination).  The LDS destination of one wave-instruction is
 // lds_base + lane * size, so both images are lane-linear.
@@ -737,7 +766,9 @@ __device__ __forceinline__ void stage_issue(UnitStage& S, const TriRec* __restri
     }
 }
 
-// Calls f(u, triangle, record, u - unit_base[triangle]) for every work unit, one unit per lane, 64 per wave pass.  Each
+// Calls f(u, triangle, record, u - unit_base[triangle], valid) for every work unit, one unit per lane, 64 per wave pass: the 64
+// units of block u >> 6.  ALL lanes of the wave make the call, in uniform control flow (the functor may use wave-wide operations);
+// `valid` is false for the lanes beyond the last unit.  Each
 // wave works on its own: it stages through its own two LDS buffers and never meets a workgroup barrier, so a wave with a
 // long row (32 voxels, all axes) does not hold up its neighbours.  The staging is software-pipelined: a pass first reads
 // its lane's record out of the buffer that landed, THEN issues the LDS-DMA of the next pass into the other buffer and the
@@ -813,7 +844,7 @@ __device__ __forceinline__ void for_each_unit(const TriRec* __restrict__ recs, c
             if (ubnn < nUB) range(ubnn, t_lo_nn, t_hi_nn);
         }
         VX_V_T(0)
-        if (u < U) f(u, tri, r, rel);
+        f(u, tri, r, rel, u < U);
         VX_V_T(2)
         if (ubn >= nUB) break;
         ub = ubn; ubn = ubnn;
@@ -831,22 +862,32 @@ __device__ __forceinline__ void for_each_unit(const TriRec* __restrict__ recs, c
 // not depend on x (two box axes, the three e x X axes, n.x) is evaluated once per row and can reject the whole row.
 // Hit bits are assembled in a register and leave the lane as at most two atomicOr (one when X % 32 == 0).
 // ------------------------------------------------------------------------------------------------------------
+#ifdef VX_VOX_FILTER_COHERENT  // experiment: the filter's loads at agent scope (past the XCD's L2)
+#define VX_FILTER_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#else
+#define VX_FILTER_LOAD(p) (*(p))
+#endif
 template <bool EPS, bool STORE_MASK>
 __global__ __launch_bounds__(256) void k_voxelize(const TriRec* __restrict__ recs, const uint32_t* __restrict__ unit_base,
                                                   const uint32_t* __restrict__ block_tri, uint32_t ntri, GridParams g, uint32_t* __restrict__ words,
                                                   uint64_t wb, uint64_t we, uint32_t* __restrict__ unit_mask, unsigned long long* set_calls,
-                                                  const uint32_t* __restrict__ ext /*null unless the grid has an axis above 65535 cells*/)
+                                                  const uint32_t* __restrict__ ext /*null unless the grid has an axis above 65535 cells*/,
+                                                  uint32_t* __restrict__ block_hits /*optional, with unit_mask: hits per block of 64 units*/,
+                                                  uint32_t tiles_y /*0: `words` is the reference's bitmask; else: the tiled build mask, see k_untile*/, uint32_t xw)
 {
     __shared__ UnitStage stage[kStagesPerBlock];
     unsigned hits = 0;
 #ifdef VX_VOX_DEBUG
     unsigned sent = 0;  // atomic requests this lane really sent
 #endif
-    for_each_unit(recs, unit_base, block_tri, ntri, stage, [&](uint32_t u, uint32_t t, const TriRec& r, uint32_t rel) {
-        const Unit w = decode_unit(r, t, rel, ext ? ext[t] : 0u);
+    for_each_unit(recs, unit_base, block_tri, ntri, stage, [&](uint32_t u, uint32_t t, const TriRec& r, uint32_t rel, bool valid) {
+        uint32_t mask = 0;
+        Unit w;
+        w.xseg = w.y = w.z = 0u;
+        if (valid) {
+        w = decode_unit(r, t, rel, ext ? ext[t] : 0u);
         const float cy = cell_centre(g.org[1], g.vs, w.y), cz = cell_centre(g.org[2], g.vs, w.z);
         const SatRow row = sat_row_setup<EPS>(r.v, cy, cz, g.half);
-        uint32_t mask = 0;
 #ifdef VX_DIAG_NO_SAT
         if (row.alive && w.x0 == 0xFFFFFFFFu) {
 #else
@@ -861,7 +902,15 @@ __global__ __launch_bounds__(256) void k_voxelize(const TriRec* __restrict__ rec
                 if (sat_row_test<EPS>(row, r.v, cx, g.half)) mask |= 1u << (x & 31u);
             }
         }
-        if (STORE_MASK) unit_mask[u] = mask;
+        }
+        if (STORE_MASK) {
+            // the hits of the block's 64 units: what the ordered emission scans instead of the 64 masks (all lanes are here)
+            if (valid) unit_mask[u] = mask;
+            if (block_hits) {
+                const uint32_t tot = wave_sum_u32(__popc(mask));
+                if ((threadIdx.x & 63u) == 0u) block_hits[u >> kUnitBlockLog2] = tot;
+            }
+        }
 #ifdef VX_VOX_DEBUG  // [6] lanes of a wave pass that have bits to set, [7] distinct first words among them
         {
             const unsigned long long act = __ballot(mask != 0);
@@ -881,11 +930,20 @@ __global__ __launch_bounds__(256) void k_voxelize(const TriRec* __restrict__ rec
         }
 #endif
         if (mask) {
-            const uint64_t i0 = (uint64_t)g.dim[0] * ((uint64_t)w.y + (uint64_t)g.dim[1] * w.z) + w.xseg;  // map3dto1d, voxelgrid.hpp:37-40
-            const uint32_t sh = (uint32_t)i0 & 31u;
-            const uint64_t wi = i0 >> 5;
-            const uint32_t lo = mask << sh;
-            const uint32_t hi = sh ? (mask >> (32u - sh)) : 0u;
+            uint64_t wi;
+            uint32_t lo, hi;
+            if (tiles_y) {  // tiled build mask (rows are whole words): the unit's word, next to those of its y and z neighbours
+                const uint64_t tile = ((uint64_t)(w.z >> 2) * tiles_y + (w.y >> 2)) * xw + (w.xseg >> 5);
+                wi = tile * 16ull + ((w.z & 3u) << 2) + (w.y & 3u);
+                lo = mask;
+                hi = 0u;
+            } else {
+                const uint64_t i0 = (uint64_t)g.dim[0] * ((uint64_t)w.y + (uint64_t)g.dim[1] * w.z) + w.xseg;  // map3dto1d, voxelgrid.hpp:37-40
+                const uint32_t sh = (uint32_t)i0 & 31u;
+                wi = i0 >> 5;
+                lo = mask << sh;
+                hi = sh ? (mask >> (32u - sh)) : 0u;
+            }
             // The atomics execute at the memory side, one 64-byte request per lane whatever the wave's address pattern: their
             // request rate (about 20 G/s for the chip), not the SAT, bounds this kernel.
 #ifdef VX_DIAG_NO_ATOMICS  // diagnostic build: price of the atomics (results are wrong)
@@ -904,8 +962,8 @@ __global__ __launch_bounds__(256) void k_voxelize(const TriRec* __restrict__ rec
             // copies of a multi-rank exchange) is covered the same way: every build clears its mask first -- k_tri_setup's threads or
             // a memset, both kernels in front of this one on the stream -- so the loads here only ever see this build's own bits
             // (tests/test_gpu_parity.py::test_rebuild_after_external_write_of_the_mask).
-            if (lo && wi >= wb && wi < we) { if ((words[wi] & lo) != lo) { atomicOr(&words[wi], lo); VX_V_SENT } hits += __popc(lo); }        // voxelgridBool.cpp:66
-            if (hi && wi + 1 >= wb && wi + 1 < we) { if ((words[wi + 1] & hi) != hi) { atomicOr(&words[wi + 1], hi); VX_V_SENT } hits += __popc(hi); }
+            if (lo && wi >= wb && wi < we) { if ((VX_FILTER_LOAD(&words[wi]) & lo) != lo) { atomicOr(&words[wi], lo); VX_V_SENT } hits += __popc(lo); }        // voxelgridBool.cpp:66
+            if (hi && wi + 1 >= wb && wi + 1 < we) { if ((VX_FILTER_LOAD(&words[wi + 1]) & hi) != hi) { atomicOr(&words[wi + 1], hi); VX_V_SENT } hits += __popc(hi); }
 #endif
         }
     });
@@ -933,39 +991,117 @@ namespace vx {
 #endif
 
 void launch_voxelize(const TriRec* recs, const uint32_t* unit_base, const uint32_t* block_tri, uint32_t ntri, const GridParams& g, int sat_variant,
-                     uint32_t* words, uint64_t wb, uint64_t we, uint32_t* unit_mask, unsigned long long* set_calls, hipStream_t s, const uint32_t* ext)
+                     uint32_t* words, uint64_t wb, uint64_t we, uint32_t* unit_mask, unsigned long long* set_calls, hipStream_t s, const uint32_t* ext,
+                     uint32_t* block_hits, bool tiled)
 {
     if (!ntri) return;
     const dim3 grid(kUnitBlocks), block(256);
+    const uint32_t ty = tiled ? (g.dim[1] + 3u) / 4u : 0u, xw = g.dim[0] / 32u;
+    if (tiled) { wb = 0; we = tiled_mask_words(g.dim); }
     if (sat_variant == 0) {
-        if (unit_mask) VX_KL((k_voxelize<true, true>), grid, block, 0, s, recs, unit_base, block_tri, ntri, g, words, wb, we, unit_mask, set_calls, ext);
-        else VX_KL((k_voxelize<true, false>), grid, block, 0, s, recs, unit_base, block_tri, ntri, g, words, wb, we, unit_mask, set_calls, ext);
+        if (unit_mask) VX_KL((k_voxelize<true, true>), grid, block, 0, s, recs, unit_base, block_tri, ntri, g, words, wb, we, unit_mask, set_calls, ext, block_hits, ty, xw);
+        else VX_KL((k_voxelize<true, false>), grid, block, 0, s, recs, unit_base, block_tri, ntri, g, words, wb, we, unit_mask, set_calls, ext, (uint32_t*)nullptr, ty, xw);
     } else {
-        if (unit_mask) VX_KL((k_voxelize<false, true>), grid, block, 0, s, recs, unit_base, block_tri, ntri, g, words, wb, we, unit_mask, set_calls, ext);
-        else VX_KL((k_voxelize<false, false>), grid, block, 0, s, recs, unit_base, block_tri, ntri, g, words, wb, we, unit_mask, set_calls, ext);
+        if (unit_mask) VX_KL((k_voxelize<false, true>), grid, block, 0, s, recs, unit_base, block_tri, ntri, g, words, wb, we, unit_mask, set_calls, ext, block_hits, ty, xw);
+        else VX_KL((k_voxelize<false, false>), grid, block, 0, s, recs, unit_base, block_tri, ntri, g, words, wb, we, unit_mask, set_calls, ext, (uint32_t*)nullptr, ty, xw);
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// K3  ordered emission with duplicates.  Work units are laid out triangle-major, then z, y, x: exactly the order
-// of the reference's loop nest (VoxelBuilder.hpp:186-195), so hit_base (exclusive scan of popc(unit_mask)) is the
-// position of a unit's first hit in VoxelGridVec::m_voxel / in the octree's pre-sort item list.
+// The tiled build mask.  The memory-side atomic unit takes one request per 64-byte line and wave instruction, and it is its request
+// rate that bounds K2.  In the reference's layout (x fastest) the words of a triangle's rows lie a row apart -- one request per
+// lane.  For grids whose rows are whole words (X % 32 == 0) an unsharded build therefore ORs into a mask in which the sixteen words
+// (32 voxels along x each) of 4 x 4 rows (y, z) share a line:
+//     word(xs, y, z) = (((z / 4) * ceil(Y / 4) + y / 4) * (X / 32) + xs) * 16 + (z % 4) * 4 + y % 4
+// -- consecutive lanes of a pass are consecutive rows of one triangle, so a triangle sends about three requests instead of ten --
+// and k_untile writes the reference's bitmask from it (through LDS, 16-byte accesses on both sides).
 // ------------------------------------------------------------------------------------------------------------
+uint64_t tiled_mask_words(const uint32_t dim[3]) { return (uint64_t)((dim[2] + 3u) / 4u) * ((dim[1] + 3u) / 4u) * (dim[0] / 32u) * 16ull; }
+
+// One workgroup = four tile rows (ty, tz) x sixteen tiles along x = 4 KiB: one 16-byte load per thread (the four y words of one z of a
+// tile), sixteen-by-sixteen transposes in LDS, one 16-byte store per thread (four consecutive words of a row of the reference's mask).
+__global__ __launch_bounds__(256) void k_untile(const uint32_t* __restrict__ tiled, uint32_t* __restrict__ words, uint32_t xw, uint32_t Y, uint32_t Z, uint32_t tiles_y,
+                                                uint32_t ntile_rows /*tiles_y * ceil(Z / 4)*/, uint32_t xchunks /*ceil(xw / 16)*/)
+{
+    __shared__ uint32_t sh[4][16][17];  // [tile row of the group][z % 4 * 4 + y % 4][tile], padded
+    const uint32_t q = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    const uint32_t grp = blockIdx.x / xchunks, x0 = (blockIdx.x - grp * xchunks) * 16u;
+    const uint32_t tr = grp * 4u + q;
+    {
+        const uint32_t xt = l >> 2, zz = l & 3u;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (tr < ntile_rows && x0 + xt < xw) v = *reinterpret_cast<const uint4*>(tiled + ((uint64_t)tr * xw + x0 + xt) * 16ull + zz * 4u);
+        sh[q][zz * 4u + 0u][xt] = v.x; sh[q][zz * 4u + 1u][xt] = v.y; sh[q][zz * 4u + 2u][xt] = v.z; sh[q][zz * 4u + 3u][xt] = v.w;
+    }
+    __syncthreads();
+    if (tr >= ntile_rows) return;
+    const uint32_t tz = tr / tiles_y, ty = tr - tz * tiles_y;
+    const uint32_t row = l >> 2, xs = x0 + (l & 3u) * 4u;
+    const uint32_t y = ty * 4u + (row & 3u), z = tz * 4u + (row >> 2);
+    if (y >= Y || z >= Z || xs >= xw) return;
+    uint32_t* dst = words + (uint64_t)xw * ((uint64_t)y + (uint64_t)Y * z) + xs;
+    const uint32_t* src = &sh[q][row][(l & 3u) * 4u];
+    if ((xw & 3u) == 0u) {
+        *reinterpret_cast<uint4*>(dst) = make_uint4(src[0], src[1], src[2], src[3]);
+    } else {
+        for (uint32_t k = 0; k < 4u && xs + k < xw; ++k) dst[k] = src[k];
+    }
+}
+
+void launch_untile(const uint32_t* tiled, uint32_t* words, const uint32_t dim[3], hipStream_t s)
+{
+    const uint32_t ty = (dim[1] + 3u) / 4u, tz = (dim[2] + 3u) / 4u, xw = dim[0] / 32u;
+    const uint64_t rows = (uint64_t)ty * tz;
+    if (!rows || !xw) return;
+    const uint32_t xchunks = (xw + 15u) / 16u;
+    const uint64_t nblk = ((rows + 3ull) / 4ull) * xchunks;  // (at most 2^37 / 32 / 16 / 4 workgroups: fits the grid's 2^31)
+    VX_KL(k_untile, dim3((unsigned)nblk), dim3(256), 0, s, tiled, words, xw, dim[1], dim[2], ty, (uint32_t)rows, xchunks);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K3  ordered emission with duplicates.  Work units are laid out triangle-major, then z, y, x: exactly the order
+// of the reference's loop nest (VoxelBuilder.hpp:186-195), so the exclusive scan of the units' hit counts is the
+// position of a unit's first hit in VoxelGridVec::m_voxel / in the octree's pre-sort item list.
+//
+// The scan is two-level: K2 leaves the hits of every block of 64 units (one wave pass), the device scan runs over those
+// (U / 64 values instead of U), and the wave that emits a block scans its 64 popcounts itself.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, uint32_t lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(v, d, 64);
+        if (lane >= (uint32_t)d) v += o;
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t select_bit(uint32_t v, uint32_t r);
+
 __global__ __launch_bounds__(256) void k_emit_units(const TriRec* __restrict__ recs, const uint32_t* __restrict__ unit_base,
                                                     const uint32_t* __restrict__ block_tri, uint32_t ntri, GridParams g,
-                                                    const uint32_t* __restrict__ unit_mask, const uint32_t* __restrict__ hit_base,
+                                                    const uint32_t* __restrict__ unit_mask, const uint32_t* __restrict__ block_base /*exclusive scan of K2's block hits*/,
                                                     vx_aabb* __restrict__ aabbs, uint64_t* __restrict__ morton, uint64_t cap /*records the output can hold*/,
                                                     const uint32_t* __restrict__ ext)
 {
     __shared__ UnitStage stage[kStagesPerBlock];
-    for_each_unit(recs, unit_base, block_tri, ntri, stage, [&](uint32_t u, uint32_t t, const TriRec& r, uint32_t rel) {
-        uint32_t mask = unit_mask[u];
+    const uint32_t lane = threadIdx.x & 63u;
+    for_each_unit(recs, unit_base, block_tri, ntri, stage, [&](uint32_t u, uint32_t t, const TriRec& r, uint32_t rel, bool valid) {
+        const uint32_t mask = valid ? unit_mask[u] : 0u;
+        const uint32_t cnt = __popc(mask);
+        const uint32_t incl = wave_incl_scan_u32(cnt, lane);
+        const uint32_t excl = incl - cnt;
+        const uint32_t T = __shfl(incl, 63, 64);  // records of this block
+        if (!T) return;
+        const uint64_t base = block_base[u >> kUnitBlockLog2];
+#ifndef VX_EMIT_OUTPUT_CENTRIC
         if (!mask) return;
         const Unit w = decode_unit(r, t, rel, ext ? ext[t] : 0u);
-        uint64_t off = hit_base[u];
-        while (mask) {
-            const uint32_t b = __ffs(mask) - 1;
-            mask &= mask - 1;
+        uint64_t off = base + excl;
+        uint32_t m = mask;
+        while (m) {
+            const uint32_t b = __ffs(m) - 1;
+            m &= m - 1;
             const uint32_t x = w.xseg + b;
             if (off >= cap) return;  // speculative emission into an existing buffer: the host re-emits after growing it
             if (aabbs) {
@@ -979,16 +1115,52 @@ __global__ __launch_bounds__(256) void k_emit_units(const TriRec* __restrict__ r
             if (morton) morton[off] = morton3d(x, w.y, w.z);  // octTree.hpp:765
             ++off;
         }
+#else
+        // OUTPUT-centric form (measured, not the default): record j of the block's contiguous output range goes to lane j % 64, which
+        // finds the unit that owns it (binary search of the 64 exclusive counts, by lane permutes) and the bit inside that unit's mask --
+        // consecutive lanes write consecutive 24-byte records whatever the units' hit counts.  42.7 us against 39 on the bench scene:
+        // the eleven permutes per 64 records cost more than the tidier stores give.
+        uint32_t xseg = 0u, y = 0u, z = 0u;
+        if (mask) {
+            const Unit w = decode_unit(r, t, rel, ext ? ext[t] : 0u);
+            xseg = w.xseg; y = w.y; z = w.z;
+        }
+        for (uint32_t j0 = 0; j0 < T; j0 += 64u) {
+            const uint32_t j = j0 + lane;
+            // owner of record j: the largest lane l with excl[l] <= j (units without hits share their count with the next one and lose)
+            uint32_t lo = 0u, hi = 64u;
+#pragma unroll
+            for (int it = 0; it < 6; ++it) {
+                const uint32_t mid = (lo + hi) >> 1;
+                const uint32_t e = __shfl(excl, (int)mid, 64);
+                if (e <= j) lo = mid; else hi = mid;
+            }
+            const uint32_t oe = __shfl(excl, (int)lo, 64), om = __shfl(mask, (int)lo, 64);
+            const uint32_t ox = __shfl(xseg, (int)lo, 64), oy = __shfl(y, (int)lo, 64), oz = __shfl(z, (int)lo, 64);
+            const uint64_t off = base + j;
+            if (j >= T || off >= cap) continue;  // (speculative emission into an existing buffer: the host re-emits after growing it)
+            const uint32_t x = ox + select_bit(om, j - oe);
+            if (aabbs) {
+                float bb[6];
+                cell_aabb(g, x, oy, oz, bb);
+                float2* o = reinterpret_cast<float2*>(aabbs + off);
+                o[0] = make_float2(bb[0], bb[1]);
+                o[1] = make_float2(bb[2], bb[3]);
+                o[2] = make_float2(bb[4], bb[5]);
+            }
+            if (morton) morton[off] = morton3d(x, oy, oz);  // octTree.hpp:765
+        }
+#endif
     });
 }
 
 void launch_emit_units(const TriRec* recs, const uint32_t* unit_base, const uint32_t* block_tri, uint32_t ntri, const GridParams& g,
-                       const uint32_t* unit_mask, const uint32_t* hit_base, vx_aabb* aabbs, uint64_t* morton, hipStream_t s, uint64_t cap, const uint32_t* ext)
+                       const uint32_t* unit_mask, const uint32_t* block_base, vx_aabb* aabbs, uint64_t* morton, hipStream_t s, uint64_t cap, const uint32_t* ext)
 {
     if (!ntri) return;
     // (bound by its stores, not by issue: 4096 workgroups -- several ragged rounds of the six a CU holds -- beat one even set: 45 us
     // with 1536, 41 with 2048, 39 with 4096)
-    VX_KL(k_emit_units, dim3(2u * kMaxBlocks), dim3(256), 0, s, recs, unit_base, block_tri, ntri, g, unit_mask, hit_base, aabbs, morton, cap, ext);
+    VX_KL(k_emit_units, dim3(VX_EMIT_BLOCKS), dim3(256), 0, s, recs, unit_base, block_tri, ntri, g, unit_mask, block_base, aabbs, morton, cap, ext);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1138,8 +1310,8 @@ __global__ __launch_bounds__(256) void k_mat_last(const TriRec* __restrict__ rec
                                                   uint8_t* __restrict__ tri_hit, const uint32_t* __restrict__ ext)
 {
     __shared__ UnitStage stage[kStagesPerBlock];
-    for_each_unit(recs, unit_base, block_tri, ntri, stage, [&](uint32_t u, uint32_t t, const TriRec& r, uint32_t rel) {
-        uint32_t mask = unit_mask[u];
+    for_each_unit(recs, unit_base, block_tri, ntri, stage, [&](uint32_t u, uint32_t t, const TriRec& r, uint32_t rel, bool valid) {
+        uint32_t mask = valid ? unit_mask[u] : 0u;
         if (!mask) return;
         tri_hit[t] = 1;
         if (!last_tri) return;
@@ -1170,15 +1342,16 @@ __global__ __launch_bounds__(256) void k_mat_ids(const uint32_t* __restrict__ la
 
 // Vec: addMatrialIfNeeded(m_voxelSet, material) -- one id per setVoxel call, in call order (the order of the Aabb list)
 __global__ __launch_bounds__(256) void k_mat_ids_calls(const TriRec* __restrict__ recs, const uint32_t* __restrict__ unit_base, const uint32_t* __restrict__ block_tri,
-                                                       uint32_t ntri, const uint32_t* __restrict__ unit_mask, const uint32_t* __restrict__ hit_base,
+                                                       uint32_t ntri, const uint32_t* __restrict__ unit_mask, const uint32_t* __restrict__ block_base /*as in k_emit_units*/,
                                                        const int32_t* __restrict__ tri_value, const int16_t* __restrict__ value_index, int16_t* __restrict__ out)
 {
     __shared__ UnitStage stage[kStagesPerBlock];
-    for_each_unit(recs, unit_base, block_tri, ntri, stage, [&](uint32_t u, uint32_t t, const TriRec&, uint32_t) {
-        const uint32_t n = __popc(unit_mask[u]);
+    for_each_unit(recs, unit_base, block_tri, ntri, stage, [&](uint32_t u, uint32_t t, const TriRec&, uint32_t, bool valid) {
+        const uint32_t n = valid ? __popc(unit_mask[u]) : 0u;
+        const uint32_t incl = wave_incl_scan_u32(n, threadIdx.x & 63u);  // (all lanes)
         if (!n) return;
         const int16_t id = value_index[tri_value[t]];
-        const uint32_t off = hit_base[u];
+        const uint32_t off = block_base[u >> kUnitBlockLog2] + (incl - n);
         for (uint32_t k = 0; k < n; ++k) out[off + k] = id;
     });
 }
@@ -1195,10 +1368,10 @@ void launch_mat_ids(const uint32_t* last_tri, uint64_t n, const int32_t* tri_val
     VX_KL(k_mat_ids, dim3(grid_for(n, 256, kMaxBlocks)), dim3(256), 0, s, last_tri, n, tri_value, value_index, out);
 }
 void launch_mat_ids_calls(const TriRec* recs, const uint32_t* unit_base, const uint32_t* block_tri, uint32_t ntri, const uint32_t* unit_mask,
-                          const uint32_t* hit_base, const int32_t* tri_value, const int16_t* value_index, int16_t* out, hipStream_t s)
+                          const uint32_t* block_base, const int32_t* tri_value, const int16_t* value_index, int16_t* out, hipStream_t s)
 {
     if (!ntri) return;
-    VX_KL(k_mat_ids_calls, dim3(kMaxBlocks), dim3(256), 0, s, recs, unit_base, block_tri, ntri, unit_mask, hit_base, tri_value, value_index, out);
+    VX_KL(k_mat_ids_calls, dim3(kMaxBlocks), dim3(256), 0, s, recs, unit_base, block_tri, ntri, unit_mask, block_base, tri_value, value_index, out);
 }
 
 __global__ void k_set_bit(uint32_t* words, uint64_t idx) { atomicOr(&words[idx >> 5], 1u << (idx & 31)); }
