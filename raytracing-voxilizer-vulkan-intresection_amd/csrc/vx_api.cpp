@@ -554,9 +554,10 @@ vx_status ensure_prefix(vx_grid* g)
     return prefix_finish(g, pending);
 }
 
-vx_status ensure_coarse(vx_grid* g)
+// from_tiled: the reference's bitmask has not been written yet -- the brick kernel reads the tiled build mask (g->twords) and writes it on the way
+vx_status ensure_coarse(vx_grid* g, bool from_tiled = false)
 {
-    if (g->coarse_valid) return VX_OK;
+    if (g->coarse_valid && !from_tiled) return VX_OK;
     DeviceGuard dg(g->device);
     for (int a = 0; a < 3; ++a) {
         g->cdim[a] = (g->g.dim[a] + vx::kCoarse - 1) / vx::kCoarse;
@@ -570,7 +571,7 @@ vx_status ensure_coarse(vx_grid* g)
     // bitmask -> brick-major slabs in three orientations -> level-1 mip (from the z orientation) -> level-2 mip
     const bool fuse_mip1 = !(getenv("VOXHIP_FUSE_MIP1") && atoi(getenv("VOXHIP_FUSE_MIP1")) == 0);  // 0: the separate kernel, every brick stored (tests)
     const bool fused = vx::launch_build_bricks3(g->words.as<uint32_t>(), g->g.dim, g->cdim, g->bricks.as<unsigned long long>(),
-                                                fuse_mip1 ? g->cwords.as<uint32_t>() : nullptr, g->stream);
+                                                fuse_mip1 ? g->cwords.as<uint32_t>() : nullptr, g->stream, from_tiled ? g->twords.as<uint32_t>() : nullptr);
     if (!fused) vx::launch_brick_mip1(g->bricks.as<unsigned long long>() + 2ull * nc * 8ull, nc, g->cwords.as<uint32_t>(), g->stream);
     vx::launch_build_mip2(g->cwords.as<uint32_t>(), g->cdim, g->c2dim, g->c2words.as<uint32_t>(), g->stream);
     g->coarse_valid = true;
@@ -965,7 +966,11 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
     }
     vx::launch_voxelize(g->recs.as<vx::TriRec>(), g->ubase.as<uint32_t>(), g->btri.as<uint32_t>(), ntri, g->g, o.sat_variant,
                         tiled ? g->twords.as<uint32_t>() : g->words.as<uint32_t>(), wb, we, umask, ds->set_calls, s, xw, bhits, tiled);
-    if (tiled) vx::launch_untile(g->twords.as<uint32_t>(), g->words.as<uint32_t>(), g->g.dim, s);
+    // (the tiled mask -> the reference's bitmask: by the brick kernel on its way when the traversal structure is built right away, below)
+    static const bool eager = !(getenv("VOXHIP_EAGER") && atoi(getenv("VOXHIP_EAGER")) == 0);
+    static const bool fuse_untile = !(getenv("VOXHIP_FUSE_UNTILE") && atoi(getenv("VOXHIP_FUSE_UNTILE")) == 0);
+    const bool untile_in_bricks = tiled && eager && fuse_untile;
+    if (tiled && !untile_in_bricks) vx::launch_untile(g->twords.as<uint32_t>(), g->words.as<uint32_t>(), g->g.dim, s);
     g->counts_valid = false;
     bool hits_tagged = false, occ_tagged = false, occ_queued = false;
     if (g->kind == VX_GRID_VEC) {
@@ -976,9 +981,8 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
     // bounds, mips = the reference's acceleration-structure build, hello_vulkan.cpp:700-703) and the word prefix (getAabbs /
     // primitive ids) -- behind the voxelizer instead of lazily in front of the first query.  For the Vec flavour this work
     // runs while the host waits for the hit count.  VOXHIP_EAGER=0 keeps it lazy.
-    static const bool eager = !(getenv("VOXHIP_EAGER") && atoi(getenv("VOXHIP_EAGER")) == 0);
     if (eager && wb == 0 && we == g->g.nwords) {
-        VX_TRY(ensure_coarse(g));
+        VX_TRY(ensure_coarse(g, untile_in_bricks));
         bool pending = false;
         occ_queued = !g->prefix_valid;
         VX_TRY(prefix_launch(g, &pending, mtag, &occ_tagged));

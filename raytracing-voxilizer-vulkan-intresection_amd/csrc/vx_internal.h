@@ -121,7 +121,9 @@ void launch_emit_morton_aabbs(const uint64_t* items, uint64_t n, const float roo
 //            bit z*8+y per x slab, orientation 1 bit x*8+z per y slab
 //   w1       one bit per brick (dims d1), x-fastest;   w2: one bit per 8^3 bricks (dims d2)
 // (m1 given and bdim[0] % 64 == 0: the brick kernel writes the level-1 mip itself, leaves empty bricks unwritten and returns true)
-bool launch_build_bricks3(const uint32_t* words, const uint32_t dim[3], const uint32_t bdim[3], unsigned long long* bricks3, uint32_t* m1, hipStream_t s);
+bool launch_build_bricks3(const uint32_t* words, const uint32_t dim[3], const uint32_t bdim[3], unsigned long long* bricks3, uint32_t* m1, hipStream_t s,
+                          const uint32_t* tiled = nullptr /*the voxelizer's tiled build mask (dim[0] % 32 == 0): the source instead of `words`, and `words`
+                                                            is WRITTEN from it -- launch_untile's job done on the way*/);
 void launch_brick_mip1(const unsigned long long* bricks_z /*orientation 2*/, uint64_t nbricks, uint32_t* m1, hipStream_t s);
 void launch_build_mip2(const uint32_t* m1, const uint32_t d1[3], const uint32_t d2[3], uint32_t* m2, hipStream_t s);
 struct TraceMips {

@@ -748,6 +748,9 @@ constexpr unsigned kUnitBlocks = VX_UNIT_BLOCKS;
 #ifndef VX_EMIT_BLOCKS
 #define VX_EMIT_BLOCKS (2u * kMaxBlocks)
 #endif
+#ifndef VX_EMIT_NBUF
+#define VX_EMIT_NBUF 1
+#endif
 
 // Asynchronous global -> LDS copies (gfx950 LDS-DMA: no VGPR destination).  The LDS destination of one wave-instruction is
 // lds_base + lane * size, so both images are lane-linear.
@@ -775,9 +778,9 @@ __device__ __forceinline__ void stage_issue(UnitStage& S, const TriRec* __restri
 // scalar loads of the range of the pass after it, and only then runs the functor -- so the one s_waitcnt vmcnt(0) at the top
 // of a pass finds the copies complete.  (The order matters: the compiler orders every LDS read after all LDS-DMA in flight,
 // whichever buffer it targets, and a range load that feeds arithmetic is waited for where the arithmetic stands.)
-template <class F>
+template <int NBUF = 2, class F>
 __device__ __forceinline__ void for_each_unit(const TriRec* __restrict__ recs, const uint32_t* __restrict__ unit_base,
-                                              const uint32_t* __restrict__ block_tri, uint32_t ntri, UnitStage* stages /*[kStagesPerBlock]*/, F&& f)
+                                              const uint32_t* __restrict__ block_tri, uint32_t ntri, UnitStage* stages /*[NBUF * 4]*/, F&& f)
 {
     const uint32_t U = unit_base[ntri];
     const uint32_t nUB = (U + 63u) >> kUnitBlockLog2;
@@ -787,7 +790,7 @@ __device__ __forceinline__ void for_each_unit(const TriRec* __restrict__ recs, c
     // consecutive waves of the machine take consecutive blocks: neighbours share record cache lines
     uint32_t ub = blockIdx.x * (blockDim.x >> 6) + wave;
     if (ub >= nUB) return;
-    UnitStage* S2 = stages + 2u * wave;
+    UnitStage* S2 = stages + (uint32_t)NBUF * wave;
 #ifdef VX_VOX_DEBUG
     unsigned long long vdbg[6] = {0, 0, 0, 0, 0, 0}, vlast = __builtin_readcyclecounter();
 #endif
@@ -810,7 +813,7 @@ __device__ __forceinline__ void for_each_unit(const TriRec* __restrict__ recs, c
         // this pass's staging (issued one pass ago by this wave) has landed
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         VX_V_T(4)
-        const UnitStage& S = S2[cur];
+        const UnitStage& S = S2[NBUF == 2 ? cur : 0];
         const uint32_t u = (ub << kUnitBlockLog2) + lane;
         const uint32_t n = t_hi - t_lo + 1u;
         const bool staged = t_hi - t_lo < kStageTris;
@@ -840,7 +843,10 @@ __device__ __forceinline__ void for_each_unit(const TriRec* __restrict__ recs, c
         const uint32_t ubnn = ubn + stride;
         uint32_t t_lo_nn = 0u, t_hi_nn = 0u;
         if (ubn < nUB) {
-            if (t_hi_n - t_lo_n < kStageTris) stage_issue(S2[cur ^ 1], recs, unit_base, t_lo_n, t_hi_n - t_lo_n + 1u, lane);
+            // (NBUF == 1: into the buffer this pass has just read -- its reads have returned: the waits the compiler puts in front of the
+            // first use of their results stand above this point in program order, and LDS operations of a wave complete in order)
+            if (NBUF == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (t_hi_n - t_lo_n < kStageTris) stage_issue(S2[NBUF == 2 ? (cur ^ 1) : 0], recs, unit_base, t_lo_n, t_hi_n - t_lo_n + 1u, lane);
             if (ubnn < nUB) range(ubnn, t_lo_nn, t_hi_nn);
         }
         VX_V_T(0)
@@ -864,6 +870,8 @@ __device__ __forceinline__ void for_each_unit(const TriRec* __restrict__ recs, c
 // ------------------------------------------------------------------------------------------------------------
 #ifdef VX_VOX_FILTER_COHERENT  // experiment: the filter's loads at agent scope (past the XCD's L2)
 #define VX_FILTER_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#elif defined(VX_VOX_NO_FILTER)  // experiment: every lane with bits sends its request
+#define VX_FILTER_LOAD(p) 0u
 #else
 #define VX_FILTER_LOAD(p) (*(p))
 #endif
@@ -896,10 +904,30 @@ __global__ __launch_bounds__(256) void k_voxelize(const TriRec* __restrict__ rec
             // (a two-sweep form -- box x + plane on every voxel, the six edge axes on the survivors only -- is slower: the
             // wave pays for its lane with the most survivors, 0.21 ms vs 0.18 ms; unrolled by two, the sweep needs twice the
             // registers for no gain)
+            // The x range is K2a's, trimmed with the box-axis test along x: the sweep leaves that test out (sat_row_test, BOXX).  (x + 0.5f
+            // is carried as a float: exact below 2^23, one conversion less per voxel.)
+            float xh = (float)w.x0 + 0.5f;
+            uint32_t bit = 1u << (w.x0 & 31u);
+#ifndef VX_SAT_ONE_LOOP
+            // EPS variant: when no lane's row can have an axis shorter than the threshold, the sweep without those checks
+            if (EPS && !__any(!sat_row_all_live(row))) {
 #pragma clang loop unroll(disable) vectorize(disable)
-            for (uint32_t x = w.x0; x < w.x1; ++x) {
-                const float cx = cell_centre(g.org[0], g.vs, x);
-                if (sat_row_test<EPS>(row, r.v, cx, g.half)) mask |= 1u << (x & 31u);
+                for (uint32_t x = w.x0; x < w.x1; ++x) {
+                    const float cx = g.org[0] + (xh * g.vs);  // cell_centre
+                    if (sat_row_test<EPS, false, false>(row, r.v, cx, g.half)) mask |= bit;
+                    xh += 1.0f;
+                    bit <<= 1;
+                }
+            } else
+#endif
+            {
+#pragma clang loop unroll(disable) vectorize(disable)
+                for (uint32_t x = w.x0; x < w.x1; ++x) {
+                    const float cx = g.org[0] + (xh * g.vs);  // cell_centre
+                    if (sat_row_test<EPS, false>(row, r.v, cx, g.half)) mask |= bit;
+                    xh += 1.0f;
+                    bit <<= 1;
+                }
             }
         }
         }
@@ -962,8 +990,16 @@ __global__ __launch_bounds__(256) void k_voxelize(const TriRec* __restrict__ rec
             // copies of a multi-rank exchange) is covered the same way: every build clears its mask first -- k_tri_setup's threads or
             // a memset, both kernels in front of this one on the stream -- so the loads here only ever see this build's own bits
             // (tests/test_gpu_parity.py::test_rebuild_after_external_write_of_the_mask).
-            if (lo && wi >= wb && wi < we) { if ((VX_FILTER_LOAD(&words[wi]) & lo) != lo) { atomicOr(&words[wi], lo); VX_V_SENT } hits += __popc(lo); }        // voxelgridBool.cpp:66
-            if (hi && wi + 1 >= wb && wi + 1 < we) { if ((VX_FILTER_LOAD(&words[wi + 1]) & hi) != hi) { atomicOr(&words[wi + 1], hi); VX_V_SENT } hits += __popc(hi); }
+            // (The tiled build mask needs no filter: its requests are few enough for the memory side, and without the loads the wave does
+            // not wait for anything between its sweep and its next pass: 71.3 -> 69.2 us.)
+            if (tiles_y) {
+                atomicOr(&words[wi], lo);  // voxelgridBool.cpp:66
+                VX_V_SENT
+                hits += __popc(lo);
+            } else {
+                if (lo && wi >= wb && wi < we) { if ((VX_FILTER_LOAD(&words[wi]) & lo) != lo) { atomicOr(&words[wi], lo); VX_V_SENT } hits += __popc(lo); }        // voxelgridBool.cpp:66
+                if (hi && wi + 1 >= wb && wi + 1 < we) { if ((VX_FILTER_LOAD(&words[wi + 1]) & hi) != hi) { atomicOr(&words[wi + 1], hi); VX_V_SENT } hits += __popc(hi); }
+            }
 #endif
         }
     });
@@ -1084,9 +1120,12 @@ __global__ __launch_bounds__(256) void k_emit_units(const TriRec* __restrict__ r
                                                     vx_aabb* __restrict__ aabbs, uint64_t* __restrict__ morton, uint64_t cap /*records the output can hold*/,
                                                     const uint32_t* __restrict__ ext)
 {
-    __shared__ UnitStage stage[kStagesPerBlock];
+    // One staging buffer per wave: 13 KiB of LDS per workgroup, eight workgroups (every wave slot) per CU instead of six.  This kernel waits
+    // for its own stores -- a wave's memory operations retire in issue order, so the staging of its next pass waits for the records of this
+    // one -- and more waves in flight are what hides that.
+    __shared__ UnitStage stage[VX_EMIT_NBUF * 4];
     const uint32_t lane = threadIdx.x & 63u;
-    for_each_unit(recs, unit_base, block_tri, ntri, stage, [&](uint32_t u, uint32_t t, const TriRec& r, uint32_t rel, bool valid) {
+    for_each_unit<VX_EMIT_NBUF>(recs, unit_base, block_tri, ntri, stage, [&](uint32_t u, uint32_t t, const TriRec& r, uint32_t rel, bool valid) {
         const uint32_t mask = valid ? unit_mask[u] : 0u;
         const uint32_t cnt = __popc(mask);
         const uint32_t incl = wave_incl_scan_u32(cnt, lane);

@@ -114,24 +114,30 @@ VX_HD SatRow sat_row_setup(const float v[9], float cy, float cz, float h)
     return r;
 }
 
-template <bool EPS>
+// BOXX = false leaves out the box-axis test along x.  Only for callers that sweep x over a range trimmed with that very test (K2a's
+// trim_axis: the same cell_centre, the same v - c, the same min3 / max3 against half): float subtraction and cell_centre are monotone, so
+// the test separates on a prefix and a suffix of the x range only, and the trimmed range has neither.
+// LIVE = false leaves out the EPS variant's "axis too short" checks.  Only for callers that know every one of them to be false from the
+// row's own constants: |e.z| + |e.x| >= |e.z| in float, so an axis with |e.z| >= 1e-8 (e x Y), |e.y| >= 1e-8 (e x Z) or |n.x| >= 1e-8
+// (the normal) is tested whatever x is (sat_row_all_live).
+template <bool EPS, bool BOXX = true, bool LIVE = true>
 VX_HD bool sat_row_test(const SatRow& r, const float v[9], float cx, float h)
 {
     const float p0x = v[0] - cx, p1x = v[3] - cx, p2x = v[6] - cx;
     const float e0x = p1x - p0x, e1x = p2x - p1x, e2x = p0x - p2x;
-    bool sep = (min3(p0x, p1x, p2x) > h) | (max3(p0x, p1x, p2x) < -h);           // box axis x   :90-92
+    bool sep = BOXX ? ((min3(p0x, p1x, p2x) > h) | (max3(p0x, p1x, p2x) < -h)) : false;   // box axis x   :90-92
     // e x Y = (e.z, 0, -e.x): R = h.x*|e.z| + h.z*|e.x|; d = p.x*e.z + (-(p.z*e.x))          :141-143
     // e x Z = (-e.y, e.x, 0): R = h.x*|e.y| + h.y*|e.x|; d = (-(p.x*e.y)) + p.y*e.x          :145-147
 #define VX_AXIS_YZ(ex, ey, ez)                                                               \
     {                                                                                        \
         const float Ry = h * fabsf(ez) + h * fabsf(ex);                                      \
-        const bool livey = !EPS || !((fabsf(ez) + fabsf(ex)) < 1e-8f);                       \
+        const bool livey = !EPS || !LIVE || !((fabsf(ez) + fabsf(ex)) < 1e-8f);             \
         const float a0 = p0x * (ez) + (-(r.p0z * (ex)));                                     \
         const float a1 = p1x * (ez) + (-(r.p1z * (ex)));                                     \
         const float a2 = p2x * (ez) + (-(r.p2z * (ex)));                                     \
         sep |= livey & separated(a0, a1, a2, Ry);                                           \
         const float Rz = h * fabsf(ey) + h * fabsf(ex);                                      \
-        const bool livez = !EPS || !((fabsf(ey) + fabsf(ex)) < 1e-8f);                       \
+        const bool livez = !EPS || !LIVE || !((fabsf(ey) + fabsf(ex)) < 1e-8f);             \
         const float b0 = (-(p0x * (ey))) + r.p0y * (ex);                                     \
         const float b1 = (-(p1x * (ey))) + r.p1y * (ex);                                     \
         const float b2 = (-(p2x * (ey))) + r.p2y * (ex);                                     \
@@ -145,11 +151,18 @@ VX_HD bool sat_row_test(const SatRow& r, const float v[9], float cx, float h)
     const float ny = r.e0z * e1x - r.e1z * e0x;
     const float nz = e0x * r.e1y - e1x * r.e0y;
     const float anx = fabsf(r.nx), any = fabsf(ny), anz = fabsf(nz);
-    const bool livep = !EPS || !(((anx + any) + anz) < 1e-8f);
+    const bool livep = !EPS || !LIVE || !(((anx + any) + anz) < 1e-8f);
     const float rr = (h * anx + h * any) + h * anz;
     const float s = (r.nx * p0x + ny * r.p0y) + nz * r.p0z;
     sep |= livep & (fabsf(s) > rr);
     return !sep;
+}
+
+// True when none of the EPS variant's x-dependent "axis too short" checks can fire on this row (see sat_row_test, LIVE)
+VX_HD bool sat_row_all_live(const SatRow& r)
+{
+    const float t = 1e-8f;
+    return (fabsf(r.e0y) >= t) & (fabsf(r.e0z) >= t) & (fabsf(r.e1y) >= t) & (fabsf(r.e1z) >= t) & (fabsf(r.e2y) >= t) & (fabsf(r.e2z) >= t) & (fabsf(r.nx) >= t);
 }
 
 // Whole test for one voxel (used by host-side checks and single-voxel paths)

@@ -74,9 +74,11 @@ __device__ __forceinline__ unsigned long long transpose8x8(unsigned long long x)
 // `m1` (optional; needs BX % 64 == 0 so that a workgroup's 64 bricks are two whole words of it): the level-1 mip, one bit per brick,
 // written from here -- and then EMPTY bricks are not stored at all (the walk never fetches a brick whose level-1 bit is clear):
 // on a surface scene that is three quarters of the 3 x N/8 bytes this kernel would write.
-__global__ __launch_bounds__(256) void k_build_bricks3(const uint32_t* __restrict__ words, uint32_t X, uint32_t Y, uint32_t Z, uint32_t BX, uint32_t BY,
+__global__ __launch_bounds__(256) void k_build_bricks3(uint32_t* __restrict__ words /*read; written when `tiled` is given*/, uint32_t X, uint32_t Y, uint32_t Z, uint32_t BX, uint32_t BY,
                                                        uint32_t BZ, uint32_t chunks_x, uint64_t nwords, unsigned long long* __restrict__ bricks3,
-                                                       uint64_t ori_stride /*uint64 words per orientation*/, uint32_t* __restrict__ m1)
+                                                       uint64_t ori_stride /*uint64 words per orientation*/, uint32_t* __restrict__ m1,
+                                                       const uint32_t* __restrict__ tiled /*optional (X % 32 == 0): the voxelizer's tiled build mask is the
+                                                       source, and `words` -- the reference's bitmask -- is WRITTEN from it on the way (k_untile's job)*/)
 {
     __shared__ uint32_t rows[64][17];              // [z*8 + y][32-voxel chunk of the 512]; padded against bank conflicts of the column reads
     __shared__ unsigned long long sz[64][9];       // [brick][z slab]: bit y*8 + x (padded)
@@ -90,7 +92,18 @@ __global__ __launch_bounds__(256) void k_build_bricks3(const uint32_t* __restric
         // (four words of one row) instead of four 4-byte loads with funnel shifts -- the kernel is bound by the latency of these
         // strided loads, not by their bytes.
         uint32_t nonzero = 0u;
-        if ((X & 127u) == 0u) {
+        if (tiled) {
+            // the group's 64 rows are 2 x 2 tile rows (y / 4, z / 4) of the tiled mask, 16 tiles of 64 bytes each: one 16-byte load per
+            // thread (the four y words of one z of a tile)
+            const uint32_t xw = X >> 5, tiles_y = (Y + 3u) >> 2, tiles_z = (Z + 3u) >> 2;
+            const uint32_t q = threadIdx.x >> 6, l = threadIdx.x & 63u;
+            const uint32_t ty = by * 2u + (q & 1u), tz = bz * 2u + (q >> 1), xt = l >> 2, zz = l & 3u, xs = cx * 16u + xt;
+            uint4 val = make_uint4(0u, 0u, 0u, 0u);
+            if (ty < tiles_y && tz < tiles_z && xs < xw) val = *reinterpret_cast<const uint4*>(tiled + (((uint64_t)tz * tiles_y + ty) * xw + xs) * 16ull + zz * 4u);
+            const uint32_t r0 = ((q >> 1) * 4u + zz) * 8u + (q & 1u) * 4u;  // row (z % 8) * 8 + y % 8 of the first of the four words
+            rows[r0][xt] = val.x; rows[r0 + 1u][xt] = val.y; rows[r0 + 2u][xt] = val.z; rows[r0 + 3u][xt] = val.w;
+            nonzero = val.x | val.y | val.z | val.w;
+        } else if ((X & 127u) == 0u) {
             const uint32_t r = threadIdx.x >> 2, q4 = (threadIdx.x & 3u) * 4u;
             const uint32_t z = bz * 8u + (r >> 3), y = by * 8u + (r & 7u), xs = x0 + q4 * 32u;
             uint4 val = make_uint4(0u, 0u, 0u, 0u);
@@ -116,15 +129,32 @@ __global__ __launch_bounds__(256) void k_build_bricks3(const uint32_t* __restric
             rows[r][j] = val;
             nonzero |= val;
         }
+        bool empty = false;
         if (m1) {
             // an empty row of 64 bricks (most of them, on a surface scene): two zero words of the mip, nothing else
-            if (!__syncthreads_or(nonzero != 0u)) {
-                if (threadIdx.x < 2u) m1[((uint64_t)cx * 64u + (uint64_t)BX * ((uint64_t)by + (uint64_t)BY * bz)) / 32u + threadIdx.x] = 0u;
-                continue;
-            }
+            empty = !__syncthreads_or(nonzero != 0u);
+            if (empty && threadIdx.x < 2u) m1[((uint64_t)cx * 64u + (uint64_t)BX * ((uint64_t)by + (uint64_t)BY * bz)) / 32u + threadIdx.x] = 0u;
         } else {
             __syncthreads();
         }
+        if (tiled) {
+            // the reference's bitmask, written from the staged rows: four consecutive words of a row per thread
+            const uint32_t xw = X >> 5;
+            const uint32_t r = threadIdx.x >> 2, q4 = (threadIdx.x & 3u) * 4u;
+            const uint32_t z = bz * 8u + (r >> 3), y = by * 8u + (r & 7u), xs = cx * 16u + q4;
+            if (z < Z && y < Y && xs < xw) {
+                uint32_t* dst = words + (uint64_t)xw * ((uint64_t)y + (uint64_t)Y * z) + xs;
+                if (empty) {
+                    if ((xw & 3u) == 0u) *reinterpret_cast<uint4*>(dst) = make_uint4(0u, 0u, 0u, 0u);
+                    else for (uint32_t k = 0; k < 4u && xs + k < xw; ++k) dst[k] = 0u;
+                } else if ((xw & 3u) == 0u) {
+                    *reinterpret_cast<uint4*>(dst) = make_uint4(rows[r][q4], rows[r][q4 + 1u], rows[r][q4 + 2u], rows[r][q4 + 3u]);
+                } else {
+                    for (uint32_t k = 0; k < 4u && xs + k < xw; ++k) dst[k] = rows[r][q4 + k];
+                }
+            }
+        }
+        if (empty) continue;  // (nothing of `rows` is read on this path: no barrier needed before the next group's loads overwrite it)
         // ---- z orientation (bit y*8 + x per z slab): two (brick, slab) pairs per thread, into LDS
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -190,7 +220,8 @@ __global__ __launch_bounds__(256) void k_build_bricks3(const uint32_t* __restric
 }
 
 // Returns true when the level-1 mip was written by the brick kernel itself (and empty bricks were left unwritten).
-bool launch_build_bricks3(const uint32_t* words, const uint32_t dim[3], const uint32_t bdim[3], unsigned long long* bricks3, uint32_t* m1, hipStream_t s)
+bool launch_build_bricks3(const uint32_t* words, const uint32_t dim[3], const uint32_t bdim[3], unsigned long long* bricks3, uint32_t* m1, hipStream_t s,
+                          const uint32_t* tiled)
 {
     const uint64_t n = (uint64_t)bdim[0] * bdim[1] * bdim[2];
     if (!n) return false;
@@ -201,8 +232,8 @@ bool launch_build_bricks3(const uint32_t* words, const uint32_t dim[3], const ui
     uint64_t nblk = ngroups;
     if (nblk > 16384) nblk = 16384;
     const bool fused = (bdim[0] % 64u) == 0u && m1 != nullptr;
-    VX_KL(k_build_bricks3, dim3((unsigned)nblk), dim3(256), 0, s, words, dim[0], dim[1], dim[2], bdim[0], bdim[1], bdim[2], chunks_x, nwords, bricks3, n * 8ull,
-          fused ? m1 : nullptr);
+    VX_KL(k_build_bricks3, dim3((unsigned)nblk), dim3(256), 0, s, const_cast<uint32_t*>(words), dim[0], dim[1], dim[2], bdim[0], bdim[1], bdim[2], chunks_x, nwords, bricks3, n * 8ull,
+          fused ? m1 : nullptr, (dim[0] % 32u) == 0u ? tiled : nullptr);
     return fused;
 }
 
