@@ -303,7 +303,7 @@ struct vx_grid {
     float bbmin[3] = {0, 0, 0}, bbmax[3] = {0, 0, 0}, bbc[3] = {0, 0, 0};
     uint64_t triangles = 0;
     uint32_t cdim[3] = {0, 0, 0}, c2dim[3] = {0, 0, 0};
-    DevBuf words, twords /*tiled build mask (launch_voxelize)*/, cwords, c2words, bricks, idxtmp, ttmp, camera, wprefix, wsel /*word of every 1024th occupied voxel (prefix scan)*/, recs, ext /*high bits of the candidate ranges*/, units, ubase, btri, umask, bhits /*hits per block of 64 units*/, hbase /*their exclusive scan*/, scantmp, small, vec, matids, mattmp;
+    DevBuf words, twords /*tiled build mask (launch_voxelize)*/, cwords, c2words, bricks, idxtmp, ttmp, camera, wprefix, wsel /*word of every 1024th occupied voxel (prefix scan)*/, wp16 /*every 16th entry of wprefix, dense (prefix scan)*/, recs, ext /*high bits of the candidate ranges*/, units, ubase, btri, umask, bhits /*hits per block of 64 units*/, hbase /*their exclusive scan*/, scantmp, small, vec, matids, mattmp;
     std::vector<vx_material> materials;  // m_materials: distinct values in first-use order (VX_VOXELIZE_MATERIALS builds only)
     uint64_t mat_count = 0;              // entries of matids
     bool has_materials = false;
@@ -334,18 +334,18 @@ struct vx_grid {
     void set_dev(int d)
     {
         device = d;
-        for (DevBuf* b : {&words, &twords, &cwords, &c2words, &bricks, &idxtmp, &ttmp, &camera, &wprefix, &wsel, &recs, &ext, &units, &ubase, &btri, &umask, &bhits, &hbase, &scantmp, &small, &vec, &matids, &mattmp}) b->dev = d;
+        for (DevBuf* b : {&words, &twords, &cwords, &c2words, &bricks, &idxtmp, &ttmp, &camera, &wprefix, &wsel, &wp16, &recs, &ext, &units, &ubase, &btri, &umask, &bhits, &hbase, &scantmp, &small, &vec, &matids, &mattmp}) b->dev = d;
     }
     // the stream this handle queues work on; the pool orders the reuse of released blocks by it
     void set_stream(hipStream_t st)
     {
         if (st != stream && words.p) (void)hipStreamSynchronize(stream);  // work queued on the old stream must not outlive the switch
         stream = st;
-        for (DevBuf* b : {&words, &twords, &cwords, &c2words, &bricks, &idxtmp, &ttmp, &camera, &wprefix, &wsel, &recs, &ext, &units, &ubase, &btri, &umask, &bhits, &hbase, &scantmp, &small, &vec, &matids, &mattmp}) b->stream = st;
+        for (DevBuf* b : {&words, &twords, &cwords, &c2words, &bricks, &idxtmp, &ttmp, &camera, &wprefix, &wsel, &wp16, &recs, &ext, &units, &ubase, &btri, &umask, &bhits, &hbase, &scantmp, &small, &vec, &matids, &mattmp}) b->stream = st;
     }
     void release_all()
     {
-        for (DevBuf* b : {&words, &twords, &cwords, &c2words, &bricks, &idxtmp, &ttmp, &camera, &wprefix, &wsel, &recs, &ext, &units, &ubase, &btri, &umask, &bhits, &hbase, &scantmp, &small, &vec, &matids, &mattmp}) b->release();
+        for (DevBuf* b : {&words, &twords, &cwords, &c2words, &bricks, &idxtmp, &ttmp, &camera, &wprefix, &wsel, &wp16, &recs, &ext, &units, &ubase, &btri, &umask, &bhits, &hbase, &scantmp, &small, &vec, &matids, &mattmp}) b->release();
         if (mail) (void)hipHostFree(mail);
         mail = nullptr;
     }
@@ -523,9 +523,10 @@ vx_status prefix_launch(vx_grid* g, bool* pending, unsigned long long tag = 0, b
     VX_HIP(g->wprefix.ensure((size_t)(g->g.nwords + 2) * 4));
     VX_HIP(g->wsel.ensure((size_t)(g->g.nwords / 32 + 4) * 4));  // at most 32 nwords / 1024 chunks of 1024 records
     VX_HIP(ensure_scan_tmp(g->scantmp, vx::scan_tmp_bytes(g->g.nwords), g->stream));
+    VX_HIP(g->wp16.ensure((size_t)(g->g.nwords / 16 + 4) * 4));
     const bool tg = vx::launch_scan_u32(g->words.as<uint32_t>(), g->wprefix.as<uint32_t>(), g->g.nwords, true, g->scantmp.p, &g->mail->occupied, g->stream, true, tag,
-                                        g->wsel.as<uint32_t>(), next_scan_gen(g->scantmp, g->stream));
-    g->sel_valid = tg;  // (the three-pass scan does not write it)
+                                        g->wsel.as<uint32_t>(), next_scan_gen(g->scantmp, g->stream), g->wp16.as<uint32_t>());
+    g->sel_valid = tg;  // (the three-pass scan writes neither wsel nor wp16)
     if (tagged) *tagged = tg;
     g->occ_tag = tg ? tag : 0;  // what the host may poll the mailbox for instead of draining the stream (prefix_finish)
     g->prefix_valid = true;
@@ -1614,7 +1615,10 @@ static vx_status trace_common(vx_grid* g, vx::TraceIO io)
         VX_HIP(hipStreamSynchronize(g->stream));  // the host copy lives on the caller's stack
         io.cam_dev = g->camera.as<vx::Camera>();
     }
-    vx::launch_trace(g->g, mips, prefix, io, g->small.as<Small>()->trace_counters, &g->trace_phase, idx_tmp, g->stream);
+    static const bool rank16 = !(getenv("VOXHIP_RANK16") && atoi(getenv("VOXHIP_RANK16")) == 0);
+    // (the mask is allocated with two spare words, so a rank may read its voxel's whole 16-word group only when that lies inside: nwords % 16 == 0)
+    const uint32_t* p16 = (prefix && g->sel_valid && rank16 && (g->g.nwords % 16) == 0) ? g->wp16.as<uint32_t>() : nullptr;
+    vx::launch_trace(g->g, mips, prefix, io, g->small.as<Small>()->trace_counters, &g->trace_phase, idx_tmp, g->stream, p16);
     VX_HIP(hipGetLastError());
     return VX_OK;
 }

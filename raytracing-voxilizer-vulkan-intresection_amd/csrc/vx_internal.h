@@ -74,7 +74,9 @@ size_t scan_tmp_bytes(uint64_t n);
 bool launch_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, bool popcount_input, void* tmp,
                      unsigned long long* total64, hipStream_t s, bool tmp_is_zero = false, unsigned long long total_tag = 0,
                      uint32_t* sel1024 = nullptr /*optional (single-pass kernel only, values <= 1024): sel1024[c] = the element whose range holds c * 1024*/,
-                     uint32_t gen = 0 /*generation mode (vx_kernels.hip): the number of this scan on `tmp`, 1, 2, 3 ... < 2^22; 0 = tickets + self-cleaning state*/);
+                     uint32_t gen = 0 /*generation mode (vx_kernels.hip): the number of this scan on `tmp`, 1, 2, 3 ... < 2^22; 0 = tickets + self-cleaning state*/,
+                     uint32_t* group16 = nullptr /*optional (single-pass kernel only): group16[i] = out[16 i], n / 16 + 1 entries -- a dense array small
+                                                   enough to stay in L2 for readers that gather (k_rank)*/);
 
 void launch_scan_u8(const uint8_t* in, uint32_t* out, uint64_t n, void* tmp /*scan_tmp_bytes(n), all zero*/, unsigned long long* total64, hipStream_t s,
                     unsigned long long total_tag = 0, uint32_t gen = 0);
@@ -153,7 +155,8 @@ struct TraceIO {
 inline bool trace_idx32(const GridParams& g) { return g.nvox < 0xFFFFFFFFull; }
 inline size_t trace_idx_bytes(const GridParams& g, uint64_t nrays) { return (size_t)nrays * (trace_idx32(g) ? 4 : 8) + 8; }
 void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* word_prefix, const TraceIO& io, unsigned long long* counters /*2 device words, zero before the first trace; they alternate*/, int* phase /*host*/,
-                  void* idx_tmp /*trace_idx_bytes when ranks / normals / the hit list are wanted*/, hipStream_t s);
+                  void* idx_tmp /*trace_idx_bytes when ranks / normals / the hit list are wanted*/, hipStream_t s,
+                  const uint32_t* prefix16 = nullptr /*optional: launch_scan_u32's group16 of word_prefix*/);
 
 // single-voxel helpers
 void launch_set_bit(uint32_t* words, uint64_t idx, hipStream_t s);

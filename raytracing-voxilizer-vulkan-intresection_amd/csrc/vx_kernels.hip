@@ -314,7 +314,8 @@ __global__ __launch_bounds__(kOneBlock) void k_scan_onepass(const uint32_t* __re
                                                            unsigned long long* status /*[0]: ticket, [1]: finished tiles, [2 + tile]: state*/, uint32_t ntiles,
                                                            unsigned long long* total, unsigned long long total_tag /*OR-ed into *total: bits 48..63*/,
                                                            uint32_t* __restrict__ sel /*optional: sel[c] = index of the element whose range [pre, pre + v) holds c * 1024*/,
-                                                           uint32_t gen /*0: tickets + self-cleaning state; else generation mode*/)
+                                                           uint32_t gen /*0: tickets + self-cleaning state; else generation mode*/,
+                                                           uint32_t* __restrict__ group16 /*optional: group16[i] = out[16 i], a dense copy of every 16th output*/)
 {
     __shared__ unsigned wsum[kOneBlock / 64];
     __shared__ unsigned tile_s;
@@ -414,6 +415,8 @@ __global__ __launch_bounds__(kOneBlock) void k_scan_onepass(const uint32_t* __re
     }
     __syncthreads();
     pre += (unsigned)prefix_s;
+    static_assert(kOneItems == 16, "group16: one group per thread");
+    if (group16 && base <= n) group16[base >> 4] = pre;
     if (full) {  // all outputs of this thread exist (out has n + 1 entries)
 #pragma unroll
         for (int q = 0; q < kOneItems / 4; ++q) {
@@ -456,7 +459,7 @@ __global__ __launch_bounds__(kOneBlock) void k_scan_onepass(const uint32_t* __re
 size_t scan_tmp_bytes(uint64_t n) { return (size_t)(((n + 1) + kScanTile - 1) / kScanTile + 4) * sizeof(unsigned long long); }
 
 bool launch_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, bool popcount_input, void* tmp, unsigned long long* total64,
-                     hipStream_t s, bool tmp_is_zero, unsigned long long total_tag, uint32_t* sel1024, uint32_t gen)
+                     hipStream_t s, bool tmp_is_zero, unsigned long long total_tag, uint32_t* sel1024, uint32_t gen, uint32_t* group16)
 {
     const uint32_t nblocks = (uint32_t)(((n + 1) + kScanTile - 1) / kScanTile);
     unsigned long long* status = (unsigned long long*)tmp;
@@ -468,8 +471,8 @@ bool launch_scan_u32(const uint32_t* in, uint32_t* out, uint64_t n, bool popcoun
         // first (they hold older scans' words) and runs with tickets, which leaves them zero again.
         const uint32_t g = (gen && ntiles <= kScanGenTiles) ? gen : 0u;
         if (!g && (!tmp_is_zero || gen)) (void)hipMemsetAsync(status, 0, (size_t)(ntiles + 2) * sizeof(unsigned long long), s);
-        if (popcount_input) VX_KL(k_scan_onepass<1>, dim3(ntiles), dim3(kOneBlock), 0, s, in, out, n, status, ntiles, total64, total_tag, sel1024, g);
-        else VX_KL(k_scan_onepass<0>, dim3(ntiles), dim3(kOneBlock), 0, s, in, out, n, status, ntiles, total64, total_tag, sel1024, g);
+        if (popcount_input) VX_KL(k_scan_onepass<1>, dim3(ntiles), dim3(kOneBlock), 0, s, in, out, n, status, ntiles, total64, total_tag, sel1024, g, group16);
+        else VX_KL(k_scan_onepass<0>, dim3(ntiles), dim3(kOneBlock), 0, s, in, out, n, status, ntiles, total64, total_tag, sel1024, g, group16);
         return true;
     }
     unsigned long long* sums = status;
@@ -493,7 +496,7 @@ void launch_scan_u8(const uint8_t* in, uint32_t* out, uint64_t n, void* tmp, uns
     const uint32_t g = (gen && ntiles <= kScanGenTiles) ? gen : 0u;
     if (!g && gen) (void)hipMemsetAsync(tmp, 0, (size_t)(ntiles + 2) * sizeof(unsigned long long), s);
     VX_KL(k_scan_onepass<2>, dim3(ntiles), dim3(kOneBlock), 0, s, reinterpret_cast<const uint32_t*>(in), out, n, (unsigned long long*)tmp, ntiles, total64, total_tag,
-          (uint32_t*)nullptr, g);
+          (uint32_t*)nullptr, g, (uint32_t*)nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------------------
