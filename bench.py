@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--verify-rays", type=int, default=1000)
     ap.add_argument("--big-rays", type=int, default=8_000_000, help="extra untimed-for-`value` measurement: trace throughput on a large batch (0 = skip)")
     ap.add_argument("--pipelined-steps", type=int, default=40, help="extra untimed-for-`value` measurement: this many steps with two in flight on two streams (0 = skip)")
+    ap.add_argument("--sync-list", action="store_true",
+                    help="VoxelGridVec: queue the list's emission inside the build (default: VX_VOXELIZE_LIST_ASYNC -- the build knows the list's length, "
+                         "the records are written beside the step's own ray batch, on a low-priority side stream of the grid handle)")
     ap.add_argument("--no-context", action="store_true",
                     help="skip the untimed-for-`value` context block (interior camera on this scene, BASELINE configs[1] and configs[4] trace rates)")
     ap.add_argument("--c4-grid", type=int, default=1024, help="N>1: also measure the sharded build + exchange at this resolution (0 = skip)")
@@ -310,13 +313,15 @@ def main():
     ev_all = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(stage_steps)]
     stage_ms = np.zeros(4)
 
+    list_async = kind == voxhip.GRID_VEC and not sharded and not a.sync_list
+
     def step(staged, k=0):
         timed = staged
         ev = ev_all[k] if timed else None
         if timed:
             ev[0].record()
         if not sharded:
-            grid.revoxelize(mesh, vs)
+            grid.revoxelize(mesh, vs, list_async=list_async)
         else:
             grid.revoxelize(mesh, vs, words=(wb, we))
         if timed:
@@ -548,6 +553,13 @@ def main():
             ot, op = oracle.trace_brute(oa, rays[sel], threads=ncores)
             words = grid.bitmask()
             verified = bool(np.array_equal(h_t[sel], ot) and np.array_equal(h_prim[sel], op) and np.array_equal(words, ow) and int(nocc) == (gd["set_calls"] if kind == voxhip.GRID_VEC else len(oa)))
+            if kind == voxhip.GRID_VEC and not sharded:
+                # the list itself, as the last timed step left it in the consumer's buffer (with --sync-list off: written beside that step's
+                # ray batch), byte for byte against the oracle's VoxelGridVec list
+                ov = oracle.build_vec(verts, tris, vs, threads=min(ncores, 32), cap=int(nocc))
+                torch.cuda.synchronize()
+                got = d_aabbs[: int(nocc) * 6].cpu().numpy()
+                verified = verified and len(ov) == int(nocc) and got.tobytes() == ov.tobytes()
         if not a.no_cpu_baseline:
             cpu = cpu_baseline(oracle, verts, tris, vs, rays, oa, a.cpu_ray_sample, R, a.cpu_runs)
 
@@ -556,7 +568,7 @@ def main():
     out = {
         "metric": "Mrays/s", "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic", "verified": verified,
+        "data": "synthetic", "verified": verified, "list_async": bool(list_async),
         "config": {"workload": "%s (%d tris) @ %d^3 grid, %s + %d random rays per GPU"
                    % (a.scene, T, a.grid, "VoxelGridVec build + getAabbs" if kind == voxhip.GRID_VEC else "VoxelGridBool build + getAabbs", R), "grid_dim": list(desc["dim"]), "voxel_size": float(vs), "rays_per_gpu": R,
                    "parallelism": "1 GPU" if world == 1 else "bitmask word-shards x%d + RCCL all-gather, rays independent" % world},

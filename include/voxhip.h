@@ -100,6 +100,15 @@ typedef struct vx_voxelize_opts {
                                    gets is the order of its first use over the WHOLE build, so the shards' first uses are combined
                                    first (vx_grid_material_first_use -> element-wise minimum over the shards ->
                                    vx_grid_finish_materials); an unsharded build finishes by itself. */
+#define VX_VOXELIZE_LIST_ASYNC 2 /* VX_GRID_VEC (ignored with VX_VOXELIZE_MATERIALS): the build returns with the list's LENGTH known but
+                                   without having queued the kernel that writes its records.  Nothing the library queues after a build --
+                                   traversal structure, word prefix, ray batches -- reads the list, and a ray batch ends with a long drain
+                                   in which most of the GPU idles: the next vx_trace* call on the grid queues the emission on a
+                                   low-priority side stream of the handle, beside its ray kernel.  vx_grid_aabbs_device on the BOUND
+                                   buffer (vx_grid_bind_aabbs_device) then returns the count at once; the records are complete for work
+                                   queued on the grid's stream after vx_grid_list_wait(g).  Every other reader of the list in this API
+                                   (host copies, copies into another buffer, re-binding, setVoxel, the next build, free) waits by
+                                   itself; without a ray batch in between the emission runs on the grid's stream when first asked for. */
 
 /* ---- library ------------------------------------------------------------------------------------------- */
 const char* vx_last_error(void);
@@ -203,6 +212,9 @@ vx_status vx_grid_aabbs_device(const vx_grid* g, vx_aabb* dev_out, uint64_t capa
  * binding), and vx_grid_aabbs_device(g, dev_out, ...) then has nothing left to copy.  The buffer must outlive the binding;
  * dev_out NULL / capacity 0 removes it.  No effect on the other flavours (their lists are emitted by vx_grid_aabbs_device). */
 vx_status vx_grid_bind_aabbs_device(vx_grid* g, vx_aabb* dev_out, uint64_t capacity);
+/* VX_VOXELIZE_LIST_ASYNC builds: makes the grid's stream wait for the list (queues the emission there if no ray batch has taken it
+ * along yet).  Does not block the host.  A no-op for every other build. */
+vx_status vx_grid_list_wait(vx_grid* g);
 /* getMatrials() / getMatIdx() (voxelgrid.hpp:74-89) of a grid built with VX_VOXELIZE_MATERIALS:
  *   materials     the distinct MaterialObj values in the order addMatrialIfNeeded first met them (equality = MaterialObj::operator==,
  *                 obj_loader.h:45-51: every field except ior and dissolve; a face without usemtl carries MaterialObj{});

@@ -330,6 +330,89 @@ struct vx_grid {
     uint64_t bound_cap = 0;
     bool vec_in_bound = false;  // the current list lives in `bound`, not in `vec`
     vx_aabb* vec_ptr() const { return vec_in_bound ? bound : reinterpret_cast<vx_aabb*>(vec.p); }
+    // VX_VOXELIZE_LIST_ASYNC (VX_GRID_VEC): the ordered emission of the list is not queued by the build.  Nothing that follows a build on the
+    // handle's stream -- traversal structure, word prefix, a ray batch -- reads the list; the ray kernel keeps a set of persistent workgroups
+    // on every CU and ends with a long drain in which most of the machine idles, and the emission (store-bound, 40 us on the bench scene) fits
+    // into that: the next ray batch queues it on a low-priority SIDE stream of the handle, behind an event recorded on the main stream in front
+    // of the ray kernel, so that its workgroups fill the slots the ray kernel's leave.  Whatever reads the list or overwrites what the emission
+    // reads (host / device copies of the list, re-binding, setVoxel, the next build, free) goes through list_resolve() first.
+    hipStream_t side = nullptr;
+    hipEvent_t ev_ready = nullptr, ev_list = nullptr;
+    bool list_deferred = false;  // the emission has not been queued yet (its arguments: ld)
+    bool list_pending = false;   // it has been queued on `side`; the main stream has not waited for ev_list yet
+    struct { uint32_t ntri = 0; bool ext = false; vx_aabb* tgt = nullptr; uint64_t cap = 0; } ld;
+    hipError_t side_init()
+    {
+        if (side) return hipSuccess;
+        int lo = 0, hi = 0;
+        hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);  // (lo: numerically greatest = lowest priority)
+        static const bool low_prio = !(getenv("VOXHIP_LIST_SIDE_PRIO") && atoi(getenv("VOXHIP_LIST_SIDE_PRIO")) == 0);
+        static const bool light_ev = !(getenv("VOXHIP_LIST_LIGHT_EVENTS") && atoi(getenv("VOXHIP_LIST_LIGHT_EVENTS")) == 0);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&side, hipStreamNonBlocking, low_prio ? lo : hi);
+        // (both events order streams of ONE device: no system-scope fence -- its cache write-back would stand in front of the ray kernel)
+        const unsigned evf = hipEventDisableTiming | (light_ev ? hipEventDisableSystemFence : 0u);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_ready, evf);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_list, evf);
+        return e;
+    }
+    void list_emit(hipStream_t st)
+    {
+        vx::launch_emit_units(recs.as<vx::TriRec>(), ubase.as<uint32_t>(), btri.as<uint32_t>(), ld.ntri, g, umask.as<uint32_t>(), hbase.as<uint32_t>(), ld.tgt, nullptr, st,
+                              ld.cap, ld.ext ? ext.as<uint32_t>() : nullptr);
+    }
+    // first half, BEFORE the caller queues the work the emission is to run beside; second half after it
+    hipError_t list_side_begin()
+    {
+        hipError_t e = side_init();
+        if (e == hipSuccess) e = hipEventRecord(ev_ready, stream);
+        return e;
+    }
+    // `counter`, `dry_at`: the ray kernel's work queue (vx::WalkQueue).  VOXHIP_LIST_WAIT_DRY=1 holds the emission back (hipStreamWaitValue64,
+    // no CU involved) until the kernel has handed out its last rays and only drains.  Measured and not the default: the drain frees
+    // registers wave by wave but LDS only workgroup by workgroup, the emission then needs the whole drain (155 us) and ends about when the
+    // ray kernel does -- 0.504-0.510 ms per step; started WITH the ray kernel it trickles along on the CUs that hold three of its
+    // workgroups instead of four, is done after 280 us and costs the ray kernel 2 % -- 0.499-0.512.
+    hipError_t list_side_launch(unsigned long long* counter, unsigned long long dry_at)
+    {
+        hipError_t e = hipStreamWaitEvent(side, ev_ready, 0);
+        if (e != hipSuccess) return e;
+        static const int wait_dry = getenv("VOXHIP_LIST_WAIT_DRY") ? atoi(getenv("VOXHIP_LIST_WAIT_DRY")) : 0;
+        static int can_wait = -1;
+        if (can_wait < 0) { int v = 0; can_wait = (hipDeviceGetAttribute(&v, hipDeviceAttributeCanUseStreamWaitValue, device) == hipSuccess && v) ? 1 : 0; }
+        if (wait_dry && can_wait && counter && dry_at) {
+            e = hipStreamWaitValue64(side, counter, dry_at, hipStreamWaitValueGte, ~0ull);
+            if (e != hipSuccess) return e;
+        }
+        list_emit(side);
+        e = hipEventRecord(ev_list, side);
+        list_deferred = false;
+        list_pending = true;
+        return e;
+    }
+    // work queued on the main stream after this call sees the complete list (and may overwrite what the emission read)
+    hipError_t list_resolve(bool drop_unqueued = false)
+    {
+        if (list_deferred) {
+            list_deferred = false;
+            if (!drop_unqueued) list_emit(stream);  // nobody asked for rays in between: the emission runs where it always did
+        }
+        if (list_pending) {
+            list_pending = false;
+            return hipStreamWaitEvent(stream, ev_list, 0);
+        }
+        return hipSuccess;
+    }
+    void side_release()
+    {
+        if (!side) return;
+        (void)hipStreamSynchronize(side);
+        (void)hipStreamDestroy(side);
+        if (ev_ready) (void)hipEventDestroy(ev_ready);
+        if (ev_list) (void)hipEventDestroy(ev_list);
+        side = nullptr;
+        ev_ready = ev_list = nullptr;
+        list_deferred = list_pending = false;
+    }
     Mail* mail = nullptr;
     void set_dev(int d)
     {
@@ -339,7 +422,10 @@ struct vx_grid {
     // the stream this handle queues work on; the pool orders the reuse of released blocks by it
     void set_stream(hipStream_t st)
     {
-        if (st != stream && words.p) (void)hipStreamSynchronize(stream);  // work queued on the old stream must not outlive the switch
+        if (st != stream && words.p) {  // work queued on the old stream (and beside it) must not outlive the switch
+            (void)list_resolve();
+            (void)hipStreamSynchronize(stream);
+        }
         stream = st;
         for (DevBuf* b : {&words, &twords, &cwords, &c2words, &bricks, &idxtmp, &ttmp, &camera, &wprefix, &wsel, &wp16, &recs, &ext, &units, &ubase, &btri, &umask, &bhits, &hbase, &scantmp, &small, &vec, &matids, &mattmp}) b->stream = st;
     }
@@ -812,8 +898,12 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
     if (opts) o = *opts;
     g->set_stream((hipStream_t)o.stream);
     hipStream_t s = g->stream;
+    // a list emission of the previous build that is still to come reads the unit masks, hit bases and records this build overwrites (one
+    // that was never queued is dropped: its list is about to be replaced)
+    VX_HIP(g->list_resolve(/*drop_unqueued=*/true));
     if (o.sat_variant != 0 && o.sat_variant != 1) return fail(VX_ERR_INVALID_ARG, "sat_variant must be 0 or 1");
     const bool want_mat = (o.flags & VX_VOXELIZE_MATERIALS) != 0;
+    const bool list_async = (o.flags & VX_VOXELIZE_LIST_ASYNC) != 0 && g->kind == VX_GRID_VEC && !want_mat;  // (the material ids need the hit bases on the main stream)
     if (want_mat) VX_TRY(mesh_material_values(mesh));
     g->has_materials = false;
     g->mat_pending = false;
@@ -995,28 +1085,40 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
         vx_aabb* tgt = to_bound ? g->bound : g->vec.as<vx_aabb>();
         const uint64_t cap_rec = to_bound ? g->bound_cap + 1 : (g->vec.p ? g->vec.cap / sizeof(vx_aabb) : 0);
         g->vec_in_bound = false;
-        if (cap_rec)
+        if (cap_rec && !list_async)
             vx::launch_emit_units(g->recs.as<vx::TriRec>(), g->ubase.as<uint32_t>(), g->btri.as<uint32_t>(), ntri, g->g, umask,
                                   g->hbase.as<uint32_t>(), tgt, nullptr, s, to_bound ? g->bound_cap : cap_rec, xw);
         // The host needs the hit count (and takes the occupied count along).  Both are written by scans that run BEFORE the
         // emission: the host polls the tagged mailbox words and goes on queueing work (the caller's next call: a trace) while
         // the emission still runs; a stream synchronize would wake it ~15 us after the last kernel.  VOXHIP_POLL_MAIL=0, an
         // untagged total (three-pass scan) or 5 ms without an answer: the synchronize.
+        // VX_VOXELIZE_LIST_ASYNC: only the hit count -- its scan runs in front of the traversal structure and the word prefix, so the host
+        // is back in the caller ~40 us of GPU work before the build ends and the caller's ray batch is queued in time; the occupied count
+        // (the LAST kernel's total) is fetched when somebody asks for it (prefix_finish).
         const bool occ_in_flight = g->prefix_valid && !g->occupied_known;
+        const bool occ_along = occ_in_flight && !(list_async && occ_queued && occ_tagged);
         bool got = false;
-        if (poll_mail && hits_tagged && (!occ_in_flight || (occ_queued && occ_tagged)))
-            got = mail_wait(&g->mail->hits, occ_in_flight ? &g->mail->occupied : nullptr, mtag, 5.0);
+        if (poll_mail && hits_tagged && (!occ_along || (occ_queued && occ_tagged)))
+            got = mail_wait(&g->mail->hits, occ_along ? &g->mail->occupied : nullptr, mtag, 5.0);
         if (!got) VX_HIP(hipStreamSynchronize(s));
         const unsigned long long hits = g->mail->hits & kMailValue;
         if (hits >= 0xFFFFFFFFull) return fail(VX_ERR_CAPACITY, "more than 2^32 voxel hits");
-        if (g->prefix_valid) {  // the same wait covered the occupied count
+        if (g->prefix_valid && (occ_along || !got)) {  // the same wait covered the occupied count
             if ((g->mail->occupied & kMailValue) >= 0xFFFFFFFFull) return fail(VX_ERR_CAPACITY, "more than 2^32 occupied voxels");
             g->occupied = g->mail->occupied & kMailValue;
             g->occupied_known = true;
         }
         if (hits + 1 <= cap_rec) g->vec_in_bound = to_bound;
-        if (hits + 1 > cap_rec) {
-            VX_HIP(g->vec.ensure((size_t)(hits + 1) * sizeof(vx_aabb)));
+        if (hits + 1 > cap_rec) VX_HIP(g->vec.ensure((size_t)(hits + 1) * sizeof(vx_aabb)));
+        if (list_async) {
+            // VX_VOXELIZE_LIST_ASYNC: the count is known, the records are written later -- beside the next ray batch (trace_common), or
+            // on this stream by whatever asks for them first (list_resolve)
+            g->ld.ntri = ntri;
+            g->ld.ext = xw != nullptr;
+            g->ld.tgt = g->vec_ptr();
+            g->ld.cap = g->vec_in_bound ? g->bound_cap : ~0ull;
+            g->list_deferred = hits != 0;
+        } else if (hits + 1 > cap_rec) {
             vx::launch_emit_units(g->recs.as<vx::TriRec>(), g->ubase.as<uint32_t>(), g->btri.as<uint32_t>(), ntri, g->g, umask,
                                   g->hbase.as<uint32_t>(), g->vec.as<vx_aabb>(), nullptr, s, ~0ull, xw);
         }
@@ -1373,6 +1475,7 @@ vx_status vx_grid_set_voxel(vx_grid* g, uint64_t x, uint64_t y, uint64_t z)
     const uint64_t i = x + (uint64_t)g->g.dim[0] * (y + (uint64_t)g->g.dim[1] * z);
     vx::launch_set_bit(g->words.as<uint32_t>(), i, g->stream);
     if (g->kind == VX_GRID_VEC) {
+        VX_HIP(g->list_resolve());
         // append {c - half, c + half} (voxelgridVecEncoding.cpp:27-36); the float recipe is shared with the kernels
         vx_aabb b;
         vx::cell_aabb(g->g, (uint32_t)x, (uint32_t)y, (uint32_t)z, b.minimum);
@@ -1471,8 +1574,11 @@ vx_status vx_grid_aabbs_device(const vx_grid* gc, vx_aabb* dev_out, uint64_t cap
     if (g->kind == VX_GRID_VEC) {
         if (count) *count = g->vec_count;
         const uint64_t n = cap < g->vec_count ? cap : g->vec_count;
-        if (n && dev_out && dev_out != g->vec_ptr())  // (a bound buffer already holds the list: nothing to copy)
+        if (n && dev_out && dev_out != g->vec_ptr()) {  // (a bound buffer already holds the list: nothing to copy)
+            VX_HIP(g->list_resolve());
             VX_HIP(hipMemcpyAsync(dev_out, g->vec_ptr(), (size_t)n * sizeof(vx_aabb), hipMemcpyDeviceToDevice, g->stream));
+        }
+        // (a VX_VOXELIZE_LIST_ASYNC build's list in its bound buffer: the count now, the records after vx_grid_list_wait)
         return VX_OK;
     }
     // queue the prefix scan and the emission back to back, then wait once for the count
@@ -1498,6 +1604,7 @@ vx_status vx_grid_aabbs(const vx_grid* gc, vx_aabb* host_out, uint64_t cap, uint
     const uint64_t m = cap < n ? cap : n;
     if (!m || !host_out) return VX_OK;
     if (g->kind == VX_GRID_VEC) {
+        VX_HIP(g->list_resolve());
         VX_HIP(hipMemcpyAsync(host_out, g->vec_ptr(), (size_t)m * sizeof(vx_aabb), hipMemcpyDeviceToHost, g->stream));
         VX_HIP(hipStreamSynchronize(g->stream));
         return VX_OK;
@@ -1514,9 +1621,18 @@ vx_status vx_grid_aabbs(const vx_grid* gc, vx_aabb* host_out, uint64_t cap, uint
     return VX_OK;
 }
 
+vx_status vx_grid_list_wait(vx_grid* g)
+{
+    if (!g) return fail(VX_ERR_INVALID_ARG, "null argument");
+    DeviceGuard dg(g->device);
+    VX_HIP(g->list_resolve());
+    return VX_OK;
+}
+
 vx_status vx_grid_bind_aabbs_device(vx_grid* g, vx_aabb* dev_out, uint64_t capacity)
 {
     if (!g) return fail(VX_ERR_INVALID_ARG, "null argument");
+    { DeviceGuard dg0(g->device); VX_HIP(g->list_resolve()); }
     if (g->vec_in_bound && g->vec_count) {  // keep the current list reachable: move it into the grid's own storage first
         DeviceGuard dg(g->device);
         VX_HIP(g->vec.ensure((size_t)(g->vec_count + 1) * sizeof(vx_aabb)));
@@ -1581,7 +1697,7 @@ const int16_t* vx_grid_material_ids_device(const vx_grid* g)
 void vx_grid_free(vx_grid* g)
 {
     if (!g) return;
-    { DeviceGuard dg(g->device); (void)hipStreamSynchronize(g->stream); }
+    { DeviceGuard dg(g->device); (void)g->list_resolve(/*drop_unqueued=*/true); g->side_release(); (void)hipStreamSynchronize(g->stream); }
     g->release_all();
     delete g;
 }
@@ -1615,10 +1731,14 @@ static vx_status trace_common(vx_grid* g, vx::TraceIO io)
         VX_HIP(hipStreamSynchronize(g->stream));  // the host copy lives on the caller's stack
         io.cam_dev = g->camera.as<vx::Camera>();
     }
+    const bool list_beside = g->list_deferred;  // VX_VOXELIZE_LIST_ASYNC: the list's emission goes beside this ray batch
+    if (list_beside) VX_HIP(g->list_side_begin());
     static const bool rank16 = !(getenv("VOXHIP_RANK16") && atoi(getenv("VOXHIP_RANK16")) == 0);
     // (the mask is allocated with two spare words, so a rank may read its voxel's whole 16-word group only when that lies inside: nwords % 16 == 0)
     const uint32_t* p16 = (prefix && g->sel_valid && rank16 && (g->g.nwords % 16) == 0) ? g->wp16.as<uint32_t>() : nullptr;
-    vx::launch_trace(g->g, mips, prefix, io, g->small.as<Small>()->trace_counters, &g->trace_phase, idx_tmp, g->stream, p16);
+    vx::WalkQueue wq;
+    vx::launch_trace(g->g, mips, prefix, io, g->small.as<Small>()->trace_counters, &g->trace_phase, idx_tmp, g->stream, p16, list_beside ? &wq : nullptr);
+    if (list_beside) VX_HIP(g->list_side_launch(wq.counter, wq.dry_at));
     VX_HIP(hipGetLastError());
     return VX_OK;
 }

@@ -154,9 +154,16 @@ struct TraceIO {
 // voxel indices of the hits travel from the walk to the rank pass as 32-bit words when they fit (all ones = miss)
 inline bool trace_idx32(const GridParams& g) { return g.nvox < 0xFFFFFFFFull; }
 inline size_t trace_idx_bytes(const GridParams& g, uint64_t nrays) { return (size_t)nrays * (trace_idx32(g) ? 4 : 8) + 8; }
+// The ray kernel's work queue, for whoever wants to start something when it runs dry (hipStreamWaitValue64 on another stream): the device
+// word the kernel's waves draw their chunks of rays from and the value it has reached when the last chunk is out -- from then on the launch
+// only drains (0: the static first chunks cover the batch).  Batches of more than 2^31 rays: the last launch's.
+struct WalkQueue {
+    unsigned long long* counter = nullptr;
+    unsigned long long dry_at = 0;
+};
 void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* word_prefix, const TraceIO& io, unsigned long long* counters /*2 device words, zero before the first trace; they alternate*/, int* phase /*host*/,
                   void* idx_tmp /*trace_idx_bytes when ranks / normals / the hit list are wanted*/, hipStream_t s,
-                  const uint32_t* prefix16 = nullptr /*optional: launch_scan_u32's group16 of word_prefix*/);
+                  const uint32_t* prefix16 = nullptr /*optional: launch_scan_u32's group16 of word_prefix*/, WalkQueue* queue = nullptr);
 
 // single-voxel helpers
 void launch_set_bit(uint32_t* words, uint64_t idx, hipStream_t s);

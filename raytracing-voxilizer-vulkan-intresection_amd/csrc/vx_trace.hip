@@ -207,16 +207,16 @@ __global__ __launch_bounds__(1024) void k_rank(const float* __restrict__ t, cons
     }
 }
 
-void launch_walk(const GridParams& g, const TraceMips& mips, const TraceIO& io, unsigned long long* counters, int* phase, void* idx_out, bool idx32, hipStream_t s);
+void launch_walk(const GridParams& g, const TraceMips& mips, const TraceIO& io, unsigned long long* counters, int* phase, void* idx_out, bool idx32, hipStream_t s, WalkQueue* queue);
 
 void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* word_prefix, const TraceIO& io, unsigned long long* counters /*2*/,
-                  int* phase, void* idx_tmp, hipStream_t s, const uint32_t* prefix16)
+                  int* phase, void* idx_tmp, hipStream_t s, const uint32_t* prefix16, WalkQueue* queue)
 {
     const uint64_t nrays = io.nrays;
     if (!nrays) return;
     const bool want_rank = (io.prim_out || io.hits || io.normal_out) && word_prefix && idx_tmp && io.t_out;
     const bool idx32 = trace_idx32(g);
-    launch_walk(g, mips, io, counters, phase, want_rank ? idx_tmp : nullptr, idx32, s);
+    launch_walk(g, mips, io, counters, phase, want_rank ? idx_tmp : nullptr, idx32, s, queue);
     if (want_rank) {
         if (io.hits && io.nhits) (void)hipMemsetAsync(io.nhits, 0, sizeof(unsigned long long), s);
         const unsigned rthreads = io.hits ? 1024u : 256u;  // the hit list's compaction touches the global counter once per workgroup

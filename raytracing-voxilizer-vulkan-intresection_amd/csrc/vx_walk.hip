@@ -1098,7 +1098,7 @@ namespace vx {
 #endif
 
 void launch_walk(const GridParams& g, const TraceMips& mips, const TraceIO& io, unsigned long long* counters /*[2], both zero before the first launch*/,
-                 int* phase /*host: which of the two the next launch draws from*/, void* idx_out, bool idx32, hipStream_t s)
+                 int* phase /*host: which of the two the next launch draws from*/, void* idx_out, bool idx32, hipStream_t s, WalkQueue* queue)
 {
     if (!io.nrays) return;
     const uint64_t n1 = (uint64_t)mips.d1[0] * mips.d1[1] * mips.d1[2], n2 = (uint64_t)mips.d2[0] * mips.d2[1] * mips.d2[2];
@@ -1149,6 +1149,14 @@ void launch_walk(const GridParams& g, const TraceMips& mips, const TraceIO& io, 
         uint64_t nblk = (n + VX_W_BLOCK - 1) / VX_W_BLOCK;
         if (nblk > max_blocks) nblk = max_blocks;
         const dim3 grid((unsigned)nblk), block(VX_W_BLOCK);
+        if (queue) {  // the work counter of this launch and the value it reaches when the last chunk of rays has been handed out (the kernel's own arithmetic)
+            uint32_t csz = (uint32_t)n / (2u * (VX_W_BLOCK / 64u) * (uint32_t)nblk);
+            csz = csz > (uint32_t)VX_W_CHUNK_MAX ? (uint32_t)VX_W_CHUNK_MAX : csz;
+            csz = csz < (uint32_t)VX_W_CHUNK ? (uint32_t)VX_W_CHUNK : (csz & ~63u);
+            const uint64_t sr = (uint64_t)csz * (VX_W_BLOCK / 64u) * nblk;
+            queue->counter = P.cold.next_item;
+            queue->dry_at = sr >= n ? 0ull : n - sr;
+        }
         if (lds) {
             if (idx32) VX_KL((k_walk<true, uint32_t>), grid, block, shmem, s, P); else VX_KL((k_walk<true, unsigned long long>), grid, block, shmem, s, P);
         } else if (wide) {

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(HERE, "libvoxhip.so")
 VX_OK = 0
 GRID_BOOL, GRID_AABBSTRUCT, GRID_VEC = 0, 1, 2
 VOXELIZE_MATERIALS = 1
+VOXELIZE_LIST_ASYNC = 2
 STATUS_NAMES = {0: "VX_OK", 1: "VX_ERR_INVALID_ARG", 2: "VX_ERR_PATH", 3: "VX_ERR_PARSE", 4: "VX_ERR_OUT_OF_BOUNDS",
                 5: "VX_ERR_MORTON_BITS", 6: "VX_ERR_NO_DEVICE", 7: "VX_ERR_HIP", 8: "VX_ERR_CAPACITY", 9: "VX_ERR_UNSUPPORTED"}
 
@@ -59,7 +60,7 @@ SYMBOLS = [
     "vx_voxelize", "vx_voxelize_into", "vx_voxelize_multi",
     "vx_grid_create", "vx_grid_describe", "vx_grid_set_voxel", "vx_grid_test_voxel", "vx_grid_coords", "vx_grid_bytes",
     "vx_grid_bitmask", "vx_grid_bitmask_device", "vx_grid_bitmask_device_mut", "vx_grid_refresh", "vx_grid_aabbs",
-    "vx_grid_aabbs_device", "vx_grid_bind_aabbs_device", "vx_grid_materials", "vx_grid_material_ids", "vx_grid_material_ids_device", "vx_grid_material_first_use",
+    "vx_grid_aabbs_device", "vx_grid_bind_aabbs_device", "vx_grid_list_wait", "vx_grid_materials", "vx_grid_material_ids", "vx_grid_material_ids_device", "vx_grid_material_first_use",
     "vx_grid_finish_materials", "vx_multi_create", "vx_multi_voxelize", "vx_multi_grid", "vx_multi_release_grid", "vx_multi_free", "vx_sort_u64", "vx_grid_free",
     "vx_octree_build", "vx_octree_num_items", "vx_octree_num_nodes", "vx_octree_bytes", "vx_octree_items", "vx_octree_nodes",
     "vx_octree_root_bounds", "vx_octree_aabbs", "vx_octree_aabbs_device", "vx_octree_free",
@@ -159,6 +160,7 @@ def lib():
     L.vx_grid_aabbs.argtypes = [vp, vp, C.c_uint64, u64p]
     L.vx_grid_aabbs_device.argtypes = [vp, vp, C.c_uint64, u64p]
     L.vx_grid_bind_aabbs_device.argtypes = [vp, vp, C.c_uint64]
+    L.vx_grid_list_wait.argtypes = [vp]
     L.vx_grid_materials.argtypes = [vp, vp, C.c_uint64, u64p]
     L.vx_grid_material_ids.argtypes = [vp, vp, C.c_uint64, u64p]
     L.vx_grid_material_ids_device.argtypes = [vp]
@@ -349,10 +351,10 @@ class Grid:
         _check(lib().vx_voxelize_multi(mesh.h, np.float32(voxel_size), kind, sat_variant, dv, len(devices), 1 if all_gather else 0, hs))
         return [cls(C.c_void_p(hs[i])) for i in range(n)]
 
-    def revoxelize(self, mesh, voxel_size, sat_variant=0, words=None, tris=None, stream=None, materials=False, shard=None):
+    def revoxelize(self, mesh, voxel_size, sat_variant=0, words=None, tris=None, stream=None, materials=False, shard=None, list_async=False):
         o = VoxelizeOpts()
         o.sat_variant = sat_variant
-        o.flags = VOXELIZE_MATERIALS if materials else 0
+        o.flags = (VOXELIZE_MATERIALS if materials else 0) | (VOXELIZE_LIST_ASYNC if list_async else 0)
         if shard is not None:
             o.shard_rank, o.shard_world = shard
         if words is not None:
@@ -441,6 +443,10 @@ class Grid:
     def bind_aabbs_device(self, dev_ptr, capacity):
         """VX_GRID_VEC: later revoxelize() calls build the list straight in this device buffer (None / 0 removes the binding)."""
         _check(lib().vx_grid_bind_aabbs_device(self.h, dev_ptr, capacity))
+
+    def list_wait(self):
+        """VX_VOXELIZE_LIST_ASYNC builds: work queued on the grid's stream after this call sees the complete list."""
+        _check(lib().vx_grid_list_wait(self.h))
 
     def aabbs_device(self, dev_ptr, capacity):
         n = C.c_uint64()

@@ -923,6 +923,59 @@ def test_vec_list_bound_to_caller_buffer(gpu):
     assert g.aabbs().tobytes() == oracle.build_vec(v, t, np.float32(0.031)).tobytes()
 
 
+def test_vec_list_async(gpu):
+    """VX_VOXELIZE_LIST_ASYNC: the build returns with the list's length; the records are written beside the next ray batch (side stream of
+    the handle) or on the grid's stream by whoever reads the list first.  Every path ends with the oracle's list, byte for byte."""
+    import torch
+    v, t = vx_scenes.scene("blob70k")
+    vs = np.float32(2.0 / 96)
+    mesh = gpu.Mesh.from_arrays(v, t)
+    ov = oracle.build_vec(v, t, vs)
+    ow, _, gi = oracle.build_bool(v, t, vs)
+    rays = vx_scenes.random_rays(20000, gi["bmin"], gi["bmax"], seed=5)
+    d_rays = torch.from_numpy(rays).cuda()
+    d_t = torch.zeros(len(rays), dtype=torch.float32, device="cuda")
+    d_p = torch.zeros(len(rays), dtype=torch.int32, device="cuda")
+    g = gpu.Grid.voxelize(mesh, vs, gpu.GRID_VEC)
+    t_ref, p_ref, _ = g.trace(rays)
+    cap = len(ov) + 8
+    buf = torch.zeros(cap * 6, dtype=torch.float32, device="cuda")
+    g.bind_aabbs_device(buf.data_ptr(), cap)
+    for rep in range(3):  # build -> getAabbs (count only) -> rays with the emission beside them -> the next build waits for it
+        buf.zero_()
+        torch.cuda.synchronize()
+        g.revoxelize(mesh, vs, list_async=True)
+        assert g.aabbs_device(buf.data_ptr(), cap) == len(ov)
+        g.trace_device(d_rays.data_ptr(), len(rays), d_t.data_ptr(), d_p.data_ptr())
+        g.list_wait()
+        got = buf.cpu().numpy()  # (torch's copy is ordered behind the legacy stream = the grid's stream here)
+        assert got[: len(ov) * 6].tobytes() == ov.tobytes(), rep
+        assert np.array_equal(d_t.cpu().numpy(), t_ref) and np.array_equal(d_p.cpu().numpy().view(np.uint32), p_ref)
+    # no ray batch in between: the first reader queues the emission
+    buf.zero_()
+    g.revoxelize(mesh, vs, list_async=True)
+    assert g.aabbs().tobytes() == ov.tobytes()
+    g.revoxelize(mesh, vs, list_async=True)
+    g.list_wait()
+    torch.cuda.synchronize()
+    assert buf.cpu().numpy()[: len(ov) * 6].tobytes() == ov.tobytes()
+    # an unqueued emission is dropped by the next build; setVoxel and re-binding resolve a pending one
+    g.revoxelize(mesh, vs, list_async=True)
+    g.revoxelize(mesh, vs, list_async=True)
+    g.trace_device(d_rays.data_ptr(), len(rays), d_t.data_ptr(), d_p.data_ptr())
+    g.set_voxel(0, 0, 0)
+    a = g.aabbs()
+    assert len(a) == len(ov) + 1 and a[: len(ov)].tobytes() == ov.tobytes()
+    g.bind_aabbs_device(None, 0)
+    g.revoxelize(mesh, vs, list_async=True)  # without a binding: the grid's own storage
+    g.trace_device(d_rays.data_ptr(), len(rays), d_t.data_ptr(), d_p.data_ptr())
+    assert g.aabbs().tobytes() == ov.tobytes()
+    g.revoxelize(mesh, vs, list_async=True)
+    g.trace_device(d_rays.data_ptr(), len(rays), d_t.data_ptr(), d_p.data_ptr())
+    g.free()  # with the emission possibly still running
+    torch.cuda.synchronize()
+
+
 def test_rebuild_after_external_write_of_the_mask(gpu):
     """The multi-rank exchange writes the grid's bitmask from outside the library (vx_grid_bitmask_device_mut: RCCL all-gather, peer
     copies).  A rebuild in the same handle must not see any of it: the mask is cleared by the build itself (k_tri_setup's threads
