@@ -21,6 +21,10 @@ EXTRA = os.environ.get("VOXHIP_EXTRA_FLAGS", "").split()
 FLAGS = EXTRA + ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
          "--offload-arch=" + ARCH]
 
+# per-source flags.  vx_walk.hip: SimplifyCFG turns more two-sided branches of the ray kernel into selects (default threshold 4) -- 3-4 % of
+# k_walk at 1M and at 8M rays, any value from 8 to 48; no effect on the other kernels (measured on vx_kernels.hip)
+SOURCE_FLAGS = {"vx_walk.hip": ["-mllvm", "-two-entry-phi-node-folding-threshold=16"]}
+
 SOURCES = ["vx_kernels.hip", "vx_trace.hip", "vx_walk.hip", "vx_octree.hip", "vx_sort.hip", "vx_api.cpp", "vx_obj.cpp", "vx_prof.cpp"]
 HEADERS = ["vx_math.h", "vx_internal.h", os.path.join(ROOT, "include", "voxhip.h")]
 
@@ -47,7 +51,7 @@ def build_lib(force=False, verbose=False):
     objs = []
     # a change of flags (diagnostic -D builds) invalidates every object
     stamp = os.path.join(objdir, "flags.txt")
-    flags_now = " ".join(FLAGS)
+    flags_now = " ".join(FLAGS) + " | " + repr(sorted(SOURCE_FLAGS.items()))
     flags_changed = not os.path.exists(stamp) or open(stamp).read() != flags_now
     # VOXHIP_VARIANT_ONLY=a.hip,b.hip: the extra -D flags only concern these sources (parameter sweeps of one kernel)
     only = [x for x in os.environ.get("VOXHIP_VARIANT_ONLY", "").split(",") if x]
@@ -56,7 +60,7 @@ def build_lib(force=False, verbose=False):
         obj = os.path.join(objdir, src + ".o")
         objs.append(obj)
         if force or (flags_changed and (not only or src in only)) or _newer(obj, [sp] + hdrs):
-            cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", sp, "-o", obj]
+            cmd = [HIPCC] + FLAGS + SOURCE_FLAGS.get(src, []) + ["-x", "hip", "-c", sp, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             _run(cmd)
