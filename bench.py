@@ -592,9 +592,18 @@ def main():
     if aj and a.scene == "atrium262k" and a.grid == 512 and world == 1 and "k_voxelize" in kern_all:
         avg = kern_all["k_voxelize"][0] / max(kern_all["k_voxelize"][1], 1) * 1e-3
         req = aj["k_voxelize"]["atomic_lane_requests_per_launch"]
-        out["kernel_rooflines"]["k_voxelize"].update({"bound": "memory-side atomic requests", "requests_per_launch": req,
-                                                      "achieved_Greq_per_s": round(req / avg / 1e9, 2), "peak_Greq_per_s": aj["peak_Greq_per_s"],
-                                                      "frac": round(req / avg / 1e9 / aj["peak_Greq_per_s"], 3), "source": "profiles/%s_atomics.json" % atag})
+        kv = {"requests_per_launch": req, "achieved_Greq_per_s": round(req / avg / 1e9, 2), "peak_Greq_per_s": aj["peak_Greq_per_s"],
+              "frac_of_request_rate": round(req / avg / 1e9 / aj["peak_Greq_per_s"], 3), "source": "profiles/%s_atomics.json" % atag}
+        # since the tiled build mask (round 3) the requests are few enough: the kernel is bound by VALU issue (the SAT sweep)
+        vtag, vj = load_profile_json("issue")
+        vi = ((vj or {}).get("kernels") or {}).get("k_voxelize") if not sharded else None
+        if vi:
+            wps = vi["valu_wave_insts"] / avg
+            kv.update({"bound": "valu_issue", "valu_wave_insts_per_launch": vi["valu_wave_insts"], "frac": round(wps / VALU_ISSUE_PEAK, 4),
+                       "lane_utilisation": vi.get("lane_utilisation"), "issue_source": "profiles/%s_issue.json" % vtag})
+        else:
+            kv.update({"bound": "memory-side atomic requests", "frac": kv["frac_of_request_rate"]})
+        out["kernel_rooflines"]["k_voxelize"].update(kv)
     if sharded:
         out["rccl_world"] = dist.get_world_size()
         out["exchange"] = {"algo": exch.algo, "bytes_per_rank": int(exch.bytes_per_rank), "ms": round(float(stage_ms[1]), 4),

@@ -376,11 +376,15 @@ struct vx_grid {
     {
         hipError_t e = hipStreamWaitEvent(side, ev_ready, 0);
         if (e != hipSuccess) return e;
-        static const int wait_dry = getenv("VOXHIP_LIST_WAIT_DRY") ? atoi(getenv("VOXHIP_LIST_WAIT_DRY")) : 0;
+        // VOXHIP_LIST_WAIT: 0 no hold; 1 (default) until the first wave of the ray kernel has come back to the queue for more rays -- the
+        // kernel's persistent workgroups are all placed by then, the emission cannot take their slots first (without the hold the step
+        // varies 0.499-0.55 ms from run to run); 2 until the queue is dry (VOXHIP_LIST_WAIT_DRY=1 means the same)
+        static const int wait_mode = getenv("VOXHIP_LIST_WAIT") ? atoi(getenv("VOXHIP_LIST_WAIT"))
+                                     : ((getenv("VOXHIP_LIST_WAIT_DRY") && atoi(getenv("VOXHIP_LIST_WAIT_DRY"))) ? 2 : 1);
         static int can_wait = -1;
         if (can_wait < 0) { int v = 0; can_wait = (hipDeviceGetAttribute(&v, hipDeviceAttributeCanUseStreamWaitValue, device) == hipSuccess && v) ? 1 : 0; }
-        if (wait_dry && can_wait && counter && dry_at) {
-            e = hipStreamWaitValue64(side, counter, dry_at, hipStreamWaitValueGte, ~0ull);
+        if (wait_mode && can_wait && counter && dry_at) {  // (dry_at == 0: the static first chunks cover the batch, the counter never moves)
+            e = hipStreamWaitValue64(side, counter, wait_mode == 2 ? dry_at : 1ull, hipStreamWaitValueGte, ~0ull);
             if (e != hipSuccess) return e;
         }
         list_emit(side);
