@@ -741,11 +741,13 @@ struct __attribute__((aligned(16))) UnitStage {  // one wave's staging buffer
     uint32_t base[kStageTris];
 };
 constexpr uint32_t kStagesPerBlock = 2 * 4;  // double-buffered, four waves per 256-thread workgroup
-// Grid of k_voxelize: the 26 KiB of staging buffers let SIX workgroups live on a CU (160 KiB of LDS), so 256 CUs x 6 is one even,
-// fully resident set of persistent workgroups; with 256 x 8 the last quarter ran as a second, ragged round (k_voxelize 110 -> 104 us;
-// 5 per CU: 108, 7: 125).  The emission kernels, bound by their stores, are faster with the larger grid (42 vs 45 us).
+// Grid of k_voxelize.  While the kernel was bound by the memory side's request rate, one even, fully resident set of persistent
+// workgroups was best (256 CUs x 6, the number the 26 KiB of double staging buffers allowed: 110 -> 104 us against 256 x 8).  Bound by
+// VALU issue (round 3, tiled build mask) it wants a finer split of the passes and does not need the second staging buffer: one buffer
+// per wave (13 KiB) and 3072 workgroups 63.0 us, against 69.4 (two buffers, 1536), 68.1 (one, 1536), 66.2 (two, 3072), 64.4 (one,
+// 4096), 71.4 (one, 6144); forcing eight waves per SIMD (64 VGPRs) with 2048 / 4096 workgroups 63.4 / 64.0.
 #ifndef VX_UNIT_BLOCKS
-#define VX_UNIT_BLOCKS (256 * 6)
+#define VX_UNIT_BLOCKS (256 * 12)
 #endif
 constexpr unsigned kUnitBlocks = VX_UNIT_BLOCKS;
 #ifndef VX_EMIT_BLOCKS
@@ -878,20 +880,26 @@ __device__ __forceinline__ void for_each_unit(const TriRec* __restrict__ recs, c
 #else
 #define VX_FILTER_LOAD(p) (*(p))
 #endif
+#ifndef VX_VOX_NBUF
+#define VX_VOX_NBUF 1
+#endif
+#ifndef VX_VOX_MINWG
+#define VX_VOX_MINWG 1
+#endif
 template <bool EPS, bool STORE_MASK>
-__global__ __launch_bounds__(256) void k_voxelize(const TriRec* __restrict__ recs, const uint32_t* __restrict__ unit_base,
+__global__ __launch_bounds__(256, VX_VOX_MINWG) void k_voxelize(const TriRec* __restrict__ recs, const uint32_t* __restrict__ unit_base,
                                                   const uint32_t* __restrict__ block_tri, uint32_t ntri, GridParams g, uint32_t* __restrict__ words,
                                                   uint64_t wb, uint64_t we, uint32_t* __restrict__ unit_mask, unsigned long long* set_calls,
                                                   const uint32_t* __restrict__ ext /*null unless the grid has an axis above 65535 cells*/,
                                                   uint32_t* __restrict__ block_hits /*optional, with unit_mask: hits per block of 64 units*/,
                                                   uint32_t tiles_y /*0: `words` is the reference's bitmask; else: the tiled build mask, see k_untile*/, uint32_t xw)
 {
-    __shared__ UnitStage stage[kStagesPerBlock];
+    __shared__ UnitStage stage[VX_VOX_NBUF * 4];
     unsigned hits = 0;
 #ifdef VX_VOX_DEBUG
     unsigned sent = 0;  // atomic requests this lane really sent
 #endif
-    for_each_unit(recs, unit_base, block_tri, ntri, stage, [&](uint32_t u, uint32_t t, const TriRec& r, uint32_t rel, bool valid) {
+    for_each_unit<VX_VOX_NBUF>(recs, unit_base, block_tri, ntri, stage, [&](uint32_t u, uint32_t t, const TriRec& r, uint32_t rel, bool valid) {
         uint32_t mask = 0;
         Unit w;
         w.xseg = w.y = w.z = 0u;
