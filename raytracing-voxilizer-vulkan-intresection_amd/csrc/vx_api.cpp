@@ -367,25 +367,23 @@ struct vx_grid {
         if (e == hipSuccess) e = hipEventRecord(ev_ready, stream);
         return e;
     }
-    // `counter`, `dry_at`: the ray kernel's work queue (vx::WalkQueue).  VOXHIP_LIST_WAIT_DRY=1 holds the emission back (hipStreamWaitValue64,
-    // no CU involved) until the kernel has handed out its last rays and only drains.  Measured and not the default: the drain frees
-    // registers wave by wave but LDS only workgroup by workgroup, the emission then needs the whole drain (155 us) and ends about when the
-    // ray kernel does -- 0.504-0.510 ms per step; started WITH the ray kernel it trickles along on the CUs that hold three of its
-    // workgroups instead of four, is done after 280 us and costs the ray kernel 2 % -- 0.499-0.512.
+    // `counter`, `dry_at`: the ray kernel's work queue (vx::WalkQueue), for the gate in front of the emission.  Holding the emission until the
+    // queue is DRY (VOXHIP_LIST_WAIT=2) was measured and is not the default: the drain frees registers wave by wave but LDS only workgroup
+    // by workgroup, the emission then needs the whole drain (155 us) and ends about when the ray kernel does -- 0.504-0.510 ms per step.
     hipError_t list_side_launch(unsigned long long* counter, unsigned long long dry_at)
     {
         hipError_t e = hipStreamWaitEvent(side, ev_ready, 0);
         if (e != hipSuccess) return e;
         // VOXHIP_LIST_WAIT: 0 no hold; 1 (default) until the first wave of the ray kernel has come back to the queue for more rays -- the
         // kernel's persistent workgroups are all placed by then, the emission cannot take their slots first (without the hold the step
-        // varies 0.499-0.55 ms from run to run); 2 until the queue is dry (VOXHIP_LIST_WAIT_DRY=1 means the same)
-        static const int wait_mode = getenv("VOXHIP_LIST_WAIT") ? atoi(getenv("VOXHIP_LIST_WAIT"))
-                                     : ((getenv("VOXHIP_LIST_WAIT_DRY") && atoi(getenv("VOXHIP_LIST_WAIT_DRY"))) ? 2 : 1);
-        static int can_wait = -1;
-        if (can_wait < 0) { int v = 0; can_wait = (hipDeviceGetAttribute(&v, hipDeviceAttributeCanUseStreamWaitValue, device) == hipSuccess && v) ? 1 : 0; }
-        if (wait_mode && can_wait && counter && dry_at) {  // (dry_at == 0: the static first chunks cover the batch, the counter never moves)
-            e = hipStreamWaitValue64(side, counter, wait_mode == 2 ? dry_at : 1ull, hipStreamWaitValueGte, ~0ull);
-            if (e != hipSuccess) return e;
+        // varies 0.497-0.535 ms from run to run, with it 0.489-0.494); 2 until the queue is dry (measured: slower).  The hold is a
+        // one-wave gate kernel with a time bound (vx_trace.hip: a stream-level wait on the counter hangs under serialising profilers).
+        static const int wait_mode = getenv("VOXHIP_LIST_WAIT") ? atoi(getenv("VOXHIP_LIST_WAIT")) : 1;
+        if (wait_mode && counter && dry_at) {  // (dry_at == 0: the static first chunks cover the batch, the counter never moves)
+            vx::WalkQueue q;
+            q.counter = counter;
+            q.dry_at = dry_at;
+            vx::launch_queue_gate(q, wait_mode == 2 ? dry_at : 1ull, /*timeout_us=*/wait_mode == 2 ? 2000u : 300u, side);
         }
         list_emit(side);
         e = hipEventRecord(ev_list, side);

@@ -161,6 +161,7 @@ struct WalkQueue {
     unsigned long long* counter = nullptr;
     unsigned long long dry_at = 0;
 };
+void launch_queue_gate(const WalkQueue& q, unsigned long long at_least, unsigned timeout_us, hipStream_t s);  // vx_trace.hip
 void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* word_prefix, const TraceIO& io, unsigned long long* counters /*2 device words, zero before the first trace; they alternate*/, int* phase /*host*/,
                   void* idx_tmp /*trace_idx_bytes when ranks / normals / the hit list are wanted*/, hipStream_t s,
                   const uint32_t* prefix16 = nullptr /*optional: launch_scan_u32's group16 of word_prefix*/, WalkQueue* queue = nullptr);

@@ -209,6 +209,28 @@ __global__ __launch_bounds__(1024) void k_rank(const float* __restrict__ t, cons
 
 void launch_walk(const GridParams& g, const TraceMips& mips, const TraceIO& io, unsigned long long* counters, int* phase, void* idx_out, bool idx32, hipStream_t s, WalkQueue* queue);
 
+// A gate in front of work that is to run BESIDE a ray batch on another stream (the Vec list's emission, VX_VOXELIZE_LIST_ASYNC): one wave
+// that leaves once the ray kernel's work counter has reached `at_least` -- the kernel's persistent workgroups are on the machine (or, with
+// the queue's dry value, hand out their last rays) -- or after `timeout_us`, whichever comes first.  The bound makes it safe under tools
+// that serialise the kernels of all streams (counter-collecting profilers): a stream-level wait on the counter (hipStreamWaitValue64,
+// which polls without a wave) hung three of five rocprofv3 --pmc passes there, because the waiting packet went first and the ray kernel
+// was never let through.  The counter is only ever changed by memory-side atomics: read it the same way.
+__global__ __launch_bounds__(64) void k_queue_gate(unsigned long long* counter, unsigned long long at_least, unsigned long long timeout_ticks /*100 MHz*/)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = (unsigned long long)wall_clock64();
+    for (;;) {
+        if (atomicAdd(counter, 0ull) >= at_least) break;
+        if ((unsigned long long)wall_clock64() - t0 > timeout_ticks) break;
+        __builtin_amdgcn_s_sleep(32);  // ~0.9 us at 2.4 GHz
+    }
+}
+void launch_queue_gate(const WalkQueue& q, unsigned long long at_least, unsigned timeout_us, hipStream_t s)
+{
+    if (!q.counter || !at_least) return;
+    VX_KL(k_queue_gate, dim3(1), dim3(64), 0, s, q.counter, at_least, (unsigned long long)timeout_us * 100ull);
+}
+
 void launch_trace(const GridParams& g, const TraceMips& mips, const uint32_t* word_prefix, const TraceIO& io, unsigned long long* counters /*2*/,
                   int* phase, void* idx_tmp, hipStream_t s, const uint32_t* prefix16, WalkQueue* queue)
 {
