@@ -314,6 +314,8 @@ def main():
     stage_ms = np.zeros(4)
 
     list_async = kind == voxhip.GRID_VEC and not sharded and not a.sync_list
+    # VoxelGridBool::getAabbs (the N > 1 step and --flavour bool): the same deferral through vx_grid_aabbs_device_async
+    bool_async = kind != voxhip.GRID_VEC and not a.sync_list
 
     def step(staged, k=0):
         timed = staged
@@ -331,7 +333,7 @@ def main():
             exch.run(mask)
         if timed:
             ev[2].record()
-        n = grid.aabbs_device(d_aabbs.data_ptr(), cap)
+        n = (grid.aabbs_device_async if bool_async else grid.aabbs_device)(d_aabbs.data_ptr(), cap)
         if timed:
             ev[3].record()
         grid.trace_device(d_rays.data_ptr(), a.rays, d_t.data_ptr(), d_prim.data_ptr())
@@ -553,6 +555,11 @@ def main():
             ot, op = oracle.trace_brute(oa, rays[sel], threads=ncores)
             words = grid.bitmask()
             verified = bool(np.array_equal(h_t[sel], ot) and np.array_equal(h_prim[sel], op) and np.array_equal(words, ow) and int(nocc) == (gd["set_calls"] if kind == voxhip.GRID_VEC else len(oa)))
+            if kind != voxhip.GRID_VEC:
+                # VoxelGridBool::getAabbs as the last timed step left it in the consumer's buffer, byte for byte
+                torch.cuda.synchronize()
+                got = d_aabbs[: int(nocc) * 6].cpu().numpy()
+                verified = verified and len(oa) == int(nocc) and got.tobytes() == oa.tobytes()
             if kind == voxhip.GRID_VEC and not sharded:
                 # the list itself, as the last timed step left it in the consumer's buffer (with --sync-list off: written beside that step's
                 # ray batch), byte for byte against the oracle's VoxelGridVec list
@@ -568,7 +575,7 @@ def main():
     out = {
         "metric": "Mrays/s", "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic", "verified": verified, "list_async": bool(list_async),
+        "data": "synthetic", "verified": verified, "list_async": bool(list_async or bool_async),
         "config": {"workload": "%s (%d tris) @ %d^3 grid, %s + %d random rays per GPU"
                    % (a.scene, T, a.grid, "VoxelGridVec build + getAabbs" if kind == voxhip.GRID_VEC else "VoxelGridBool build + getAabbs", R), "grid_dim": list(desc["dim"]), "voxel_size": float(vs), "rays_per_gpu": R,
                    "parallelism": "1 GPU" if world == 1 else "bitmask word-shards x%d + RCCL all-gather, rays independent" % world},

@@ -215,6 +215,11 @@ vx_status vx_grid_bind_aabbs_device(vx_grid* g, vx_aabb* dev_out, uint64_t capac
 /* VX_VOXELIZE_LIST_ASYNC builds: makes the grid's stream wait for the list (queues the emission there if no ray batch has taken it
  * along yet).  Does not block the host.  A no-op for every other build. */
 vx_status vx_grid_list_wait(vx_grid* g);
+/* vx_grid_aabbs_device for the Bool / AABBstruct flavours with the same deferral: the word prefix is queued and *count returned as usual,
+ * the kernel that writes the records into dev_out is left to the next vx_trace* call on the grid (low-priority side stream, beside its ray
+ * kernel) -- or to vx_grid_list_wait / the next build / any call that changes or reads what it needs, which queue it on the grid's stream.
+ * dev_out must stay valid until then.  VX_GRID_VEC: same as vx_grid_aabbs_device. */
+vx_status vx_grid_aabbs_device_async(const vx_grid* g, vx_aabb* dev_out, uint64_t capacity, uint64_t* count);
 /* getMatrials() / getMatIdx() (voxelgrid.hpp:74-89) of a grid built with VX_VOXELIZE_MATERIALS:
  *   materials     the distinct MaterialObj values in the order addMatrialIfNeeded first met them (equality = MaterialObj::operator==,
  *                 obj_loader.h:45-51: every field except ior and dissolve; a face without usemtl carries MaterialObj{});

@@ -340,7 +340,7 @@ struct vx_grid {
     hipEvent_t ev_ready = nullptr, ev_list = nullptr;
     bool list_deferred = false;  // the emission has not been queued yet (its arguments: ld)
     bool list_pending = false;   // it has been queued on `side`; the main stream has not waited for ev_list yet
-    struct { uint32_t ntri = 0; bool ext = false; vx_aabb* tgt = nullptr; uint64_t cap = 0; } ld;
+    struct { uint32_t ntri = 0; bool ext = false; vx_aabb* tgt = nullptr; uint64_t cap = 0; bool from_mask = false; } ld;  // from_mask: vx_grid_aabbs_device_async (K4)
     hipError_t side_init()
     {
         if (side) return hipSuccess;
@@ -357,6 +357,10 @@ struct vx_grid {
     }
     void list_emit(hipStream_t st)
     {
+        if (ld.from_mask) {  // Bool / AABBstruct: the ascending list from the bitmask and its word prefix (both complete on the main stream)
+            vx::launch_emit_bool_aabbs(words.as<uint32_t>(), wprefix.as<uint32_t>(), g, ld.tgt, ld.cap, st, sel_valid ? wsel.as<uint32_t>() : nullptr);
+            return;
+        }
         vx::launch_emit_units(recs.as<vx::TriRec>(), ubase.as<uint32_t>(), btri.as<uint32_t>(), ld.ntri, g, umask.as<uint32_t>(), hbase.as<uint32_t>(), ld.tgt, nullptr, st,
                               ld.cap, ld.ext ? ext.as<uint32_t>() : nullptr);
     }
@@ -396,7 +400,9 @@ struct vx_grid {
     {
         if (list_deferred) {
             list_deferred = false;
-            if (!drop_unqueued) list_emit(stream);  // nobody asked for rays in between: the emission runs where it always did
+            // nobody asked for rays in between: the emission runs where it always did (a caller's buffer is always filled; the grid's own
+            // Vec list may be dropped when it is about to be replaced)
+            if (!drop_unqueued || ld.from_mask) list_emit(stream);
         }
         if (list_pending) {
             list_pending = false;
@@ -1115,6 +1121,7 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
         if (list_async) {
             // VX_VOXELIZE_LIST_ASYNC: the count is known, the records are written later -- beside the next ray batch (trace_common), or
             // on this stream by whatever asks for them first (list_resolve)
+            g->ld.from_mask = false;
             g->ld.ntri = ntri;
             g->ld.ext = xw != nullptr;
             g->ld.tgt = g->vec_ptr();
@@ -1475,9 +1482,9 @@ vx_status vx_grid_set_voxel(vx_grid* g, uint64_t x, uint64_t y, uint64_t z)
     if (x >= g->g.dim[0] || y >= g->g.dim[1] || z >= g->g.dim[2]) return fail(VX_ERR_OUT_OF_BOUNDS, "Index out of bounds");
     DeviceGuard dg(g->device);
     const uint64_t i = x + (uint64_t)g->g.dim[0] * (y + (uint64_t)g->g.dim[1] * z);
+    VX_HIP(g->list_resolve());  // (a list emission still to come reads the mask / appends to the list this call changes)
     vx::launch_set_bit(g->words.as<uint32_t>(), i, g->stream);
     if (g->kind == VX_GRID_VEC) {
-        VX_HIP(g->list_resolve());
         // append {c - half, c + half} (voxelgridVecEncoding.cpp:27-36); the float recipe is shared with the kernels
         vx_aabb b;
         vx::cell_aabb(g->g, (uint32_t)x, (uint32_t)y, (uint32_t)z, b.minimum);
@@ -1557,12 +1564,14 @@ const uint32_t* vx_grid_bitmask_device(const vx_grid* g) { return g ? g->words.a
 uint32_t* vx_grid_bitmask_device_mut(vx_grid* g)
 {
     if (!g) return nullptr;
+    { DeviceGuard dg(g->device); (void)g->list_resolve(); }  // (an emission still to come reads the mask the caller is about to write)
     g->coarse_valid = g->prefix_valid = g->occupied_known = false;
     return g->words.as<uint32_t>();
 }
 vx_status vx_grid_refresh(vx_grid* g)
 {
     if (!g) return fail(VX_ERR_INVALID_ARG, "null argument");
+    { DeviceGuard dg(g->device); VX_HIP(g->list_resolve()); }
     g->coarse_valid = g->prefix_valid = g->occupied_known = false;
     VX_TRY(ensure_prefix(g));
     return ensure_coarse(g);
@@ -1584,12 +1593,36 @@ vx_status vx_grid_aabbs_device(const vx_grid* gc, vx_aabb* dev_out, uint64_t cap
         return VX_OK;
     }
     // queue the prefix scan and the emission back to back, then wait once for the count
+    VX_HIP(g->list_resolve());
     bool pending = false;
     VX_TRY(prefix_launch(g, &pending));
     if (cap && dev_out && (pending || g->occupied))
         vx::launch_emit_bool_aabbs(g->words.as<uint32_t>(), g->wprefix.as<uint32_t>(), g->g, dev_out, cap, g->stream, g->sel_valid ? g->wsel.as<uint32_t>() : nullptr);
     VX_TRY(prefix_finish(g, pending));
     if (count) *count = g->occupied;
+    VX_HIP(hipGetLastError());
+    return VX_OK;
+}
+
+vx_status vx_grid_aabbs_device_async(const vx_grid* gc, vx_aabb* dev_out, uint64_t cap, uint64_t* count)
+{
+    if (!gc) return fail(VX_ERR_INVALID_ARG, "null argument");
+    vx_grid* g = const_cast<vx_grid*>(gc);
+    if (g->kind == VX_GRID_VEC) return vx_grid_aabbs_device(gc, dev_out, cap, count);  // (a Vec list is deferred by its build: VX_VOXELIZE_LIST_ASYNC)
+    DeviceGuard dg(g->device);
+    VX_HIP(g->list_resolve());
+    // the word prefix on the grid's stream (the ray batch's primitive ids need it there anyway) and its total = the list's length; the
+    // emission itself waits for the next ray batch (trace_common) or for whoever reads the list first (list_resolve)
+    bool pending = false;
+    VX_TRY(prefix_launch(g, &pending));
+    VX_TRY(prefix_finish(g, pending));
+    if (count) *count = g->occupied;
+    if (cap && dev_out && g->occupied) {
+        g->ld.from_mask = true;
+        g->ld.tgt = dev_out;
+        g->ld.cap = cap;
+        g->list_deferred = true;
+    }
     VX_HIP(hipGetLastError());
     return VX_OK;
 }

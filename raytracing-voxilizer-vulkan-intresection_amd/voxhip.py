@@ -60,7 +60,7 @@ SYMBOLS = [
     "vx_voxelize", "vx_voxelize_into", "vx_voxelize_multi",
     "vx_grid_create", "vx_grid_describe", "vx_grid_set_voxel", "vx_grid_test_voxel", "vx_grid_coords", "vx_grid_bytes",
     "vx_grid_bitmask", "vx_grid_bitmask_device", "vx_grid_bitmask_device_mut", "vx_grid_refresh", "vx_grid_aabbs",
-    "vx_grid_aabbs_device", "vx_grid_bind_aabbs_device", "vx_grid_list_wait", "vx_grid_materials", "vx_grid_material_ids", "vx_grid_material_ids_device", "vx_grid_material_first_use",
+    "vx_grid_aabbs_device", "vx_grid_bind_aabbs_device", "vx_grid_list_wait", "vx_grid_aabbs_device_async", "vx_grid_materials", "vx_grid_material_ids", "vx_grid_material_ids_device", "vx_grid_material_first_use",
     "vx_grid_finish_materials", "vx_multi_create", "vx_multi_voxelize", "vx_multi_grid", "vx_multi_release_grid", "vx_multi_free", "vx_sort_u64", "vx_grid_free",
     "vx_octree_build", "vx_octree_num_items", "vx_octree_num_nodes", "vx_octree_bytes", "vx_octree_items", "vx_octree_nodes",
     "vx_octree_root_bounds", "vx_octree_aabbs", "vx_octree_aabbs_device", "vx_octree_free",
@@ -161,6 +161,7 @@ def lib():
     L.vx_grid_aabbs_device.argtypes = [vp, vp, C.c_uint64, u64p]
     L.vx_grid_bind_aabbs_device.argtypes = [vp, vp, C.c_uint64]
     L.vx_grid_list_wait.argtypes = [vp]
+    L.vx_grid_aabbs_device_async.argtypes = [vp, vp, C.c_uint64, u64p]
     L.vx_grid_materials.argtypes = [vp, vp, C.c_uint64, u64p]
     L.vx_grid_material_ids.argtypes = [vp, vp, C.c_uint64, u64p]
     L.vx_grid_material_ids_device.argtypes = [vp]
@@ -447,6 +448,12 @@ class Grid:
     def list_wait(self):
         """VX_VOXELIZE_LIST_ASYNC builds: work queued on the grid's stream after this call sees the complete list."""
         _check(lib().vx_grid_list_wait(self.h))
+
+    def aabbs_device_async(self, dev_ptr, capacity):
+        """vx_grid_aabbs_device_async: the count now, the records beside the next ray batch (or after list_wait())."""
+        n = C.c_uint64()
+        _check(lib().vx_grid_aabbs_device_async(self.h, dev_ptr, capacity, C.byref(n)))
+        return n.value
 
     def aabbs_device(self, dev_ptr, capacity):
         n = C.c_uint64()

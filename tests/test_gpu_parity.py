@@ -976,6 +976,52 @@ def test_vec_list_async(gpu):
     torch.cuda.synchronize()
 
 
+def test_bool_list_async(gpu):
+    """vx_grid_aabbs_device_async: VoxelGridBool::getAabbs with the emission left to the next ray batch (side stream) or to the first call
+    that reads the list or changes what it is made from; the caller's buffer always ends up with the oracle's list."""
+    import torch
+    v, t = vx_scenes.scene("blob70k")
+    vs = np.float32(2.0 / 96)
+    mesh = gpu.Mesh.from_arrays(v, t)
+    ow, _, gi = oracle.build_bool(v, t, vs)
+    oa = oracle.bool_aabbs(ow, gi, vs)
+    rays = vx_scenes.random_rays(20000, gi["bmin"], gi["bmax"], seed=6)
+    d_rays = torch.from_numpy(rays).cuda()
+    d_t = torch.zeros(len(rays), dtype=torch.float32, device="cuda")
+    d_p = torch.zeros(len(rays), dtype=torch.int32, device="cuda")
+    for kind in (gpu.GRID_BOOL, gpu.GRID_AABBSTRUCT):
+        g = gpu.Grid.voxelize(mesh, vs, kind)
+        t_ref, p_ref, _ = g.trace(rays)
+        cap = len(oa) + 8
+        buf = torch.zeros(cap * 6, dtype=torch.float32, device="cuda")
+        for rep in range(2):  # build -> getAabbs (count now) -> rays with the emission beside them
+            buf.zero_()
+            torch.cuda.synchronize()
+            g.revoxelize(mesh, vs)
+            assert g.aabbs_device_async(buf.data_ptr(), cap) == len(oa)
+            g.trace_device(d_rays.data_ptr(), len(rays), d_t.data_ptr(), d_p.data_ptr())
+            g.list_wait()
+            assert buf.cpu().numpy()[: len(oa) * 6].tobytes() == oa.tobytes(), (kind, rep)
+            assert np.array_equal(d_t.cpu().numpy(), t_ref) and np.array_equal(d_p.cpu().numpy().view(np.uint32), p_ref)
+        # no ray batch: list_wait, the next build, setVoxel each queue the emission first (with the mask and prefix it was asked for)
+        buf.zero_()
+        assert g.aabbs_device_async(buf.data_ptr(), cap) == len(oa)
+        g.list_wait()
+        assert buf.cpu().numpy()[: len(oa) * 6].tobytes() == oa.tobytes()
+        buf.zero_()
+        assert g.aabbs_device_async(buf.data_ptr(), cap) == len(oa)
+        g.revoxelize(mesh, np.float32(2.0 / 64))  # another grid: the list asked for before must still be the old one
+        torch.cuda.synchronize()
+        assert buf.cpu().numpy()[: len(oa) * 6].tobytes() == oa.tobytes()
+        g.revoxelize(mesh, vs)
+        buf.zero_()
+        assert g.aabbs_device_async(buf.data_ptr(), cap) == len(oa)
+        g.set_voxel(0, 0, 0)
+        torch.cuda.synchronize()
+        assert buf.cpu().numpy()[: len(oa) * 6].tobytes() == oa.tobytes()
+        g.free()
+
+
 def test_rebuild_after_external_write_of_the_mask(gpu):
     """The multi-rank exchange writes the grid's bitmask from outside the library (vx_grid_bitmask_device_mut: RCCL all-gather, peer
     copies).  A rebuild in the same handle must not see any of it: the mask is cleared by the build itself (k_tri_setup's threads
