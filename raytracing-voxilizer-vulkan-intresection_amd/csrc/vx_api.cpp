@@ -1019,7 +1019,15 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
     // Unsharded words, rows of whole words: the voxelizer ORs into the tiled build mask (one atomic request per 4 x 4 rows instead of one per
     // row, launch_voxelize) and launch_untile writes every word of the reference's bitmask from it.  VOXHIP_VOX_TILED=0: always the direct form.
     static const bool tiled_ok = !(getenv("VOXHIP_VOX_TILED") && atoi(getenv("VOXHIP_VOX_TILED")) == 0);
-    const bool tiled = tiled_ok && wb == 0 && we == g->g.nwords && (ex.dim[0] % 32) == 0;
+    static const bool tiled_shards = !(getenv("VOXHIP_VOX_TILED_SHARDS") && atoi(getenv("VOXHIP_VOX_TILED_SHARDS")) == 0);
+    const bool whole_words = wb == 0 && we == g->g.nwords;
+    // (a word shard goes the same way: the voxelizer keeps to the rows whose words it owns, launch_untile writes those and zeroes the rest --
+    // a second pass over the WHOLE mask per rank, so only where the mask is small against the mesh: the size rule of the clear that rides in
+    // the record kernel's threads.  atrium262k, two logical ranks on one GPU: 512^3 voxelize stage 121 -> 95 us; 1024^3 392 -> 426, hence the rule)
+    // ... and only for shards of a fifth of the mask or more: shard 0 of 2 / 4 / 8 at 512^3 (tools/shard_time.py, kernels of a rebuild)
+    // 119.7 -> 97.9 / 90.6 -> 73.3 / 55.1 -> 64.0 us -- at an eighth the un-tiling pass costs what the voxelizer no longer has to gain
+    const bool shard_small = (size_t)vx::tiled_mask_words(g->g.dim) * 4 / 256 <= (size_t)ntri && (we - wb) * 5 >= g->g.nwords;
+    const bool tiled = tiled_ok && (whole_words || (tiled_shards && shard_small)) && (ex.dim[0] % 32) == 0;
     g->last_tiled = tiled;
     if (tiled) {
         const size_t tbytes = (size_t)vx::tiled_mask_words(g->g.dim) * 4;
@@ -1068,8 +1076,8 @@ vx_status vx_voxelize_into(const vx_mesh* mesh_c, float vs, const vx_voxelize_op
     // (the tiled mask -> the reference's bitmask: by the brick kernel on its way when the traversal structure is built right away, below)
     static const bool eager = !(getenv("VOXHIP_EAGER") && atoi(getenv("VOXHIP_EAGER")) == 0);
     static const bool fuse_untile = !(getenv("VOXHIP_FUSE_UNTILE") && atoi(getenv("VOXHIP_FUSE_UNTILE")) == 0);
-    const bool untile_in_bricks = tiled && eager && fuse_untile;
-    if (tiled && !untile_in_bricks) vx::launch_untile(g->twords.as<uint32_t>(), g->words.as<uint32_t>(), g->g.dim, s);
+    const bool untile_in_bricks = tiled && eager && fuse_untile && whole_words;
+    if (tiled && !untile_in_bricks) vx::launch_untile(g->twords.as<uint32_t>(), g->words.as<uint32_t>(), g->g.dim, s, wb, we);
     g->counts_valid = false;
     bool hits_tagged = false, occ_tagged = false, occ_queued = false;
     if (g->kind == VX_GRID_VEC) {

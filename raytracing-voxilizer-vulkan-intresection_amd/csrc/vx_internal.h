@@ -93,7 +93,7 @@ void launch_voxelize(const TriRec* recs, const uint32_t* unit_base, const uint32
                      bool tiled = false /*`words` is the tiled build mask (tiled_mask_words(dim) words, dim[0] % 32 == 0, whole grid): launch_untile
                                           then writes the reference's bitmask*/);
 uint64_t tiled_mask_words(const uint32_t dim[3]);
-void launch_untile(const uint32_t* tiled, uint32_t* words, const uint32_t dim[3], hipStream_t s);
+void launch_untile(const uint32_t* tiled, uint32_t* words, const uint32_t dim[3], hipStream_t s, uint64_t wb = 0, uint64_t we = ~0ull /*the words the build owns: the others are written as zero*/);
 
 // K3: VoxelGridVec / Octree emitters: one output per set bit of unit_mask, in unit order (== reference order).  block_base[b] = position of
 // the first hit of units [64 b, 64 b + 64): the exclusive scan of launch_voxelize's block_hits.

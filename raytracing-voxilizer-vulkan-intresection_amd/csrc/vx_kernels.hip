@@ -1003,9 +1003,14 @@ __global__ __launch_bounds__(256, VX_VOX_MINWG) void k_voxelize(const TriRec* __
             // (The tiled build mask needs no filter: its requests are few enough for the memory side, and without the loads the wave does
             // not wait for anything between its sweep and its next pass: 71.3 -> 69.2 us.)
             if (tiles_y) {
-                atomicOr(&words[wi], lo);  // voxelgridBool.cpp:66
-                VX_V_SENT
-                hits += __popc(lo);
+                // (a word shard: only the rows whose word of the reference's mask lies in [wb, we) -- the z slab of a shard may begin and
+                // end inside a plane)
+                const uint64_t lin = (uint64_t)xw * ((uint64_t)w.y + (uint64_t)g.dim[1] * w.z) + (w.xseg >> 5);
+                if (lin >= wb && lin < we) {
+                    atomicOr(&words[wi], lo);  // voxelgridBool.cpp:66
+                    VX_V_SENT
+                    hits += __popc(lo);
+                }
             } else {
                 if (lo && wi >= wb && wi < we) { if ((VX_FILTER_LOAD(&words[wi]) & lo) != lo) { atomicOr(&words[wi], lo); VX_V_SENT } hits += __popc(lo); }        // voxelgridBool.cpp:66
                 if (hi && wi + 1 >= wb && wi + 1 < we) { if ((VX_FILTER_LOAD(&words[wi + 1]) & hi) != hi) { atomicOr(&words[wi + 1], hi); VX_V_SENT } hits += __popc(hi); }
@@ -1043,7 +1048,6 @@ void launch_voxelize(const TriRec* recs, const uint32_t* unit_base, const uint32
     if (!ntri) return;
     const dim3 grid(kUnitBlocks), block(256);
     const uint32_t ty = tiled ? (g.dim[1] + 3u) / 4u : 0u, xw = g.dim[0] / 32u;
-    if (tiled) { wb = 0; we = tiled_mask_words(g.dim); }
     if (sat_variant == 0) {
         if (unit_mask) VX_KL((k_voxelize<true, true>), grid, block, 0, s, recs, unit_base, block_tri, ntri, g, words, wb, we, unit_mask, set_calls, ext, block_hits, ty, xw);
         else VX_KL((k_voxelize<true, false>), grid, block, 0, s, recs, unit_base, block_tri, ntri, g, words, wb, we, unit_mask, set_calls, ext, (uint32_t*)nullptr, ty, xw);
@@ -1066,8 +1070,10 @@ uint64_t tiled_mask_words(const uint32_t dim[3]) { return (uint64_t)((dim[2] + 3
 
 // One workgroup = four tile rows (ty, tz) x sixteen tiles along x = 4 KiB: one 16-byte load per thread (the four y words of one z of a
 // tile), sixteen-by-sixteen transposes in LDS, one 16-byte store per thread (four consecutive words of a row of the reference's mask).
+// [wb, we): the words this build owns (a word shard; the whole mask otherwise) -- every OTHER word of the mask is written as zero, as a
+// sharded build leaves it (the exchange fills those in).
 __global__ __launch_bounds__(256) void k_untile(const uint32_t* __restrict__ tiled, uint32_t* __restrict__ words, uint32_t xw, uint32_t Y, uint32_t Z, uint32_t tiles_y,
-                                                uint32_t ntile_rows /*tiles_y * ceil(Z / 4)*/, uint32_t xchunks /*ceil(xw / 16)*/)
+                                                uint32_t ntile_rows /*tiles_y * ceil(Z / 4)*/, uint32_t xchunks /*ceil(xw / 16)*/, uint64_t wb, uint64_t we)
 {
     __shared__ uint32_t sh[4][16][17];  // [tile row of the group][z % 4 * 4 + y % 4][tile], padded
     const uint32_t q = threadIdx.x >> 6, l = threadIdx.x & 63u;
@@ -1085,23 +1091,26 @@ __global__ __launch_bounds__(256) void k_untile(const uint32_t* __restrict__ til
     const uint32_t row = l >> 2, xs = x0 + (l & 3u) * 4u;
     const uint32_t y = ty * 4u + (row & 3u), z = tz * 4u + (row >> 2);
     if (y >= Y || z >= Z || xs >= xw) return;
-    uint32_t* dst = words + (uint64_t)xw * ((uint64_t)y + (uint64_t)Y * z) + xs;
+    const uint64_t d0 = (uint64_t)xw * ((uint64_t)y + (uint64_t)Y * z) + xs;
+    uint32_t* dst = words + d0;
     const uint32_t* src = &sh[q][row][(l & 3u) * 4u];
-    if ((xw & 3u) == 0u) {
+    if ((xw & 3u) == 0u && d0 >= wb && d0 + 4u <= we) {
         *reinterpret_cast<uint4*>(dst) = make_uint4(src[0], src[1], src[2], src[3]);
+    } else if ((xw & 3u) == 0u && (d0 + 4u <= wb || d0 >= we)) {
+        *reinterpret_cast<uint4*>(dst) = make_uint4(0u, 0u, 0u, 0u);
     } else {
-        for (uint32_t k = 0; k < 4u && xs + k < xw; ++k) dst[k] = src[k];
+        for (uint32_t k = 0; k < 4u && xs + k < xw; ++k) dst[k] = (d0 + k >= wb && d0 + k < we) ? src[k] : 0u;
     }
 }
 
-void launch_untile(const uint32_t* tiled, uint32_t* words, const uint32_t dim[3], hipStream_t s)
+void launch_untile(const uint32_t* tiled, uint32_t* words, const uint32_t dim[3], hipStream_t s, uint64_t wb, uint64_t we)
 {
     const uint32_t ty = (dim[1] + 3u) / 4u, tz = (dim[2] + 3u) / 4u, xw = dim[0] / 32u;
     const uint64_t rows = (uint64_t)ty * tz;
     if (!rows || !xw) return;
     const uint32_t xchunks = (xw + 15u) / 16u;
     const uint64_t nblk = ((rows + 3ull) / 4ull) * xchunks;  // (at most 2^37 / 32 / 16 / 4 workgroups: fits the grid's 2^31)
-    VX_KL(k_untile, dim3((unsigned)nblk), dim3(256), 0, s, tiled, words, xw, dim[1], dim[2], ty, (uint32_t)rows, xchunks);
+    VX_KL(k_untile, dim3((unsigned)nblk), dim3(256), 0, s, tiled, words, xw, dim[1], dim[2], ty, (uint32_t)rows, xchunks, wb, we);
 }
 
 // ------------------------------------------------------------------------------------------------------------
