@@ -1606,6 +1606,10 @@ vx_status vx_grid_aabbs_device(const vx_grid* gc, vx_aabb* dev_out, uint64_t cap
     VX_TRY(prefix_launch(g, &pending));
     if (cap && dev_out && (pending || g->occupied))
         vx::launch_emit_bool_aabbs(g->words.as<uint32_t>(), g->wprefix.as<uint32_t>(), g->g, dev_out, cap, g->stream, g->sel_valid ? g->wsel.as<uint32_t>() : nullptr);
+    {   // (as in vx_grid_aabbs_device_async: the traversal structure of an externally written mask, built while the host waits)
+        static const bool eager = !(getenv("VOXHIP_EAGER") && atoi(getenv("VOXHIP_EAGER")) == 0);
+        if (eager && pending) VX_TRY(ensure_coarse(g));
+    }
     VX_TRY(prefix_finish(g, pending));
     if (count) *count = g->occupied;
     VX_HIP(hipGetLastError());
@@ -1623,6 +1627,10 @@ vx_status vx_grid_aabbs_device_async(const vx_grid* gc, vx_aabb* dev_out, uint64
     // emission itself waits for the next ray batch (trace_common) or for whoever reads the list first (list_resolve)
     bool pending = false;
     VX_TRY(prefix_launch(g, &pending));
+    // a mask written from outside (the multi-rank exchange) has no traversal structure yet: queued here, it is built while the host waits
+    // for the count instead of after it, in front of the caller's ray batch (VOXHIP_EAGER=0: left to the ray batch)
+    static const bool eager = !(getenv("VOXHIP_EAGER") && atoi(getenv("VOXHIP_EAGER")) == 0);
+    if (eager && pending) VX_TRY(ensure_coarse(g));
     VX_TRY(prefix_finish(g, pending));
     if (count) *count = g->occupied;
     if (cap && dev_out && g->occupied) {
