@@ -6,6 +6,13 @@
     consumer's device buffer (vx_grid_bind_aabbs_device); `--flavour bool` runs VoxelGridBool::getAabbs = scan + k_emit_bool
     instead)  ->  first-hit trace of R rays.
 
+    The list beside the rays (`list_async` on the line; `--sync-list` switches it off): nothing a step queues after its build reads
+    the list -- the ray kernel works on the bitmask's traversal structure -- so the build is asked to leave the kernel that writes the
+    list's records to the step's OWN ray batch (VX_VOXELIZE_LIST_ASYNC / vx_grid_aabbs_device_async in include/voxhip.h): getAabbs
+    returns the count, the records are written on a low-priority side stream of the grid handle while the ray kernel runs, and the
+    next step's build waits for them.  Every step still produces bitmask, list, t and prim before the timed region's closing
+    synchronize; the untimed check compares the list the last timed step left in the consumer's buffer byte for byte.
+
 Workload (N=1): BASELINE.json configs[2] -- the Sponza-like `atrium262k` scene (261 496 triangles, synthetic: the reference
 ships no meshes) at voxelsize 32/512 = exactly 512^3 cells, VecEncoding path, with configs[1]'s ray recipe (1M random rays,
 tmin 0.001, tmax 1e4).  The north-star target (>=10 Mrays/s on a 512^3 grid) is quoted on this grid size.
@@ -21,7 +28,8 @@ processes created before this process touches the GPU -- and relays rank 0's lin
 Timing: W untimed warm-up steps, an untimed survey pass (HIP events around EVERY kernel launch -> `kernels_survey_pass`, the
 dominant kernel), then EXACTLY K timed steps between barrier + synchronize on both sides; inside the timed region only the
 dominant kernel is bracketed by events (-> `roofline`), and the stage events are read after the region.  After the timed
-region (untimed) a sample of the traced rays is compared with the oracle's brute force -> `verified`.
+region (untimed) a sample of the traced rays is compared with the oracle's brute force, the bitmask with the oracle's and the
+AABB list in the consumer's buffer with the oracle's list -> `verified`.
 
 Prints ONE JSON line on rank 0.
 """
